@@ -1,0 +1,140 @@
+/*
+ * medgp_hip.h -- C ABI of the MI355X-native MedGP hot path (libmedgp_hip.so).
+ *
+ * This is the drop-in boundary for the per-patient negative-log-marginal-likelihood + gradient
+ * operator of bee-hive/MedGP.  Every entry point cites the reference interface it replaces
+ * ("ref:" = /root/reference/medgpc/src/...).  Plain pointers and sizes only; no C++ or torch types;
+ * never throws, never exit()s; 0 = success, negative = error (message via medgp_last_error).
+ *
+ * Threading: one medgp_ctx is used by one host thread at a time (the reference's callers are
+ * single-threaded, ref: inference/c_inference_exact.cpp:55-57); different contexts (e.g. one per GPU)
+ * are fully independent and may run concurrently.
+ *
+ * Hyper-parameter vector theta (doubles, the reference's optimiser variables, ref:
+ * core/c_hyperparam.cpp:99-122, kernel/c_kernel_LMC_SM.cpp:51-70):
+ *   kernel_index 7 (LMC-SM): [log sigma_d (D) | A_q[d][r] raw, q-major (Q*D*R) | log mu_q (Q) | log v_q (Q) | log kappa_q[d] (Q*D)]
+ *   kernel_index 8 (SM)    : [log sigma | log w_q (Q) | log mu_q (Q) | log v_q (Q)]      (D = 1)
+ *   kernel_index 0 (SE)    : [log sigma | log l | log sf]                                   (Q = D = 1)
+ * Gradients come back in the same order.
+ */
+#ifndef MEDGP_HIP_H
+#define MEDGP_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct medgp_ctx medgp_ctx;
+
+/* kernel_index values: ref main_one_train.cpp:85-93 */
+#define MEDGP_KERNEL_SE      0
+#define MEDGP_KERNEL_LMC_SM  7
+#define MEDGP_KERNEL_SM      8
+
+/* error codes */
+#define MEDGP_OK            0
+#define MEDGP_ERR_ARG      -1   /* bad argument                                   */
+#define MEDGP_ERR_HIP      -2   /* a HIP runtime call failed                      */
+#define MEDGP_ERR_NODEVICE -3   /* no usable GPU: the product has NO CPU fallback */
+#define MEDGP_ERR_CAPACITY -4   /* slot / batch / n beyond medgp_reserve          */
+
+/* prior type codes, ref: prior/c_prior.h:50-53 */
+#define MEDGP_PRIOR_NONE    -1
+#define MEDGP_PRIOR_CLAMP    0
+#define MEDGP_PRIOR_NORMAL   1
+#define MEDGP_PRIOR_LAPLACE  2
+
+/* ABI version, bumped on any signature change */
+int medgp_abi_version(void);
+
+/* number of visible HIP devices (0 if none; never initialises a context) */
+int medgp_device_count(void);
+
+/* Create a context bound to one device and one covariance family.
+ * Replaces the construction of c_kernel_* / c_likelihood_* / c_inference_* objects,
+ * ref: main_one_train.cpp:103-152 (run_model_LMC_SM / run_model_SE / run_model_SM).
+ * R is ignored for SE/SM. */
+int  medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, int R);
+void medgp_destroy(medgp_ctx *ctx);
+const char *medgp_last_error(const medgp_ctx *ctx);   /* ctx may be NULL: last create() error */
+
+/* total number of hypers H = lik + cov (ref: c_kernel_LMC_SM.cpp:64-70; gaussianMO: D) */
+int medgp_num_hyp(const medgp_ctx *ctx);
+
+/* pi used inside the kernels; default 3.14159265, the reference's literal
+ * (ref: util/global_settings.h:6) */
+int medgp_set_pi(medgp_ctx *ctx, double pi);
+
+/* Run all work of this context on the given hipStream_t (e.g. torch's current stream).
+ * NULL = the context's own stream (default). */
+int medgp_set_stream(medgp_ctx *ctx, void *hip_stream);
+
+/* (Re)allocate device storage: patient slots, largest padded n, largest batch per call.
+ * Replaces the per-evaluation new[]/delete[] of N*N buffers, ref: core/gp_regression.cpp:102-117,
+ * inference/c_inference_exact.cpp:66-68,168. Existing patients are discarded. */
+int medgp_reserve(medgp_ctx *ctx, int max_slots, int max_n, int max_batch);
+
+/* Upload one patient (meta[i] in [0,D), t = time stamps, y = z-scored values; host pointers, copied).
+ * Replaces c_objective_one's constructor, ref: util/c_objective_one.cpp:23-36 and
+ * util/c_objective_one.h:40-45.  meta may be NULL for SE/SM.  Observations are stably grouped
+ * by output internally (the reference's loader already produces that order,
+ * ref: dataio/c_experiment.cpp:272-308), which leaves nlml/gradients unchanged. */
+int medgp_set_patient(medgp_ctx *ctx, int slot, int n, const int32_t *meta, const float *t, const float *y);
+
+/* Per-hyper prior descriptor of one slot, H entries each in theta order; flag == NULL removes the prior.
+ * Replaces the public vectors of c_prior read by c_inference_prior::compute_nlml,
+ * ref: prior/c_prior.h:35-53, inference/c_inference_prior.cpp:60-150.
+ * slot = -1 applies the descriptor to every slot. */
+int medgp_set_prior(medgp_ctx *ctx, int slot, const uint8_t *flag, const int32_t *type,
+                    const uint8_t *is_exp, const float *p0, const float *p1);
+
+/* THE OPERATOR.  nbatch independent evaluations: problem b = patient slots[b] with hypers
+ * theta[b*H .. (b+1)*H).  Replaces c_objective_one::compute_objective -> GP_Regression::train ->
+ * c_inference_prior::compute_nlml -> c_inference_exact::compute_nlml,
+ * ref: util/c_objective_one.cpp:40-82, core/gp_regression.cpp:102-126,
+ *      inference/c_inference_prior.cpp:25-154, inference/c_inference_exact.cpp:29-244,
+ *      kernel/c_kernel_LMC_SM.cpp:152-327.
+ * status[b]: 0..10 = jitter rounds applied (ref: c_inference_exact.cpp:96-111); -1 = the
+ * reference's `return false` (Cholesky failed after 10 jitters, or n <= 2,
+ * ref: util/c_objective_one.cpp:51,79-81); nlml/grad of a failed problem are NaN.
+ * All pointers are HOST memory; grad may be NULL when flag_grad == 0. */
+int medgp_nlml_grad(medgp_ctx *ctx, int nbatch, const int32_t *slots, const double *theta, int flag_grad,
+                    double *nlml, double *grad, int32_t *status);
+
+/* Same operator with theta / nlml / grad / status in DEVICE memory of ctx's device; asynchronous on
+ * the context's stream (slots stays a host array: it only selects resident patients). */
+int medgp_nlml_grad_device(medgp_ctx *ctx, int nbatch, const int32_t *slots, const double *theta_dev,
+                           int flag_grad, double *nlml_dev, double *grad_dev, int32_t *status_dev);
+
+/* After medgp_nlml_grad*(…, flag_grad=1): copy out K^-1 (y - m) and L^-1 of batch entry b as the
+ * reference's float buffers (alpha[n]; linv[n*n] row-major lower, strict upper zero) in the
+ * caller's original observation order when the patient was already grouped by output.
+ * Replaces the chol_alpha / chol_factor_inv / beta outputs of c_inference::compute_nlml,
+ * ref: inference/c_inference.h:38-52, inference/c_inference_exact.cpp:124-147. Either pointer may be NULL. */
+int medgp_get_factor(medgp_ctx *ctx, int b, float *alpha, float *linv, float *beta);
+
+/* Factor once with theta, predict nstar points.  Replaces GP_Regression::train(false) + predict,
+ * ref: core/gp_regression.cpp:128-214, kernel/c_kernel_LMC_SM.cpp:329-372 (cross Gram), :122-150 (diag);
+ * caller: main_one_test.cpp:386-399.  mean/var are float like the reference. */
+int medgp_fit_predict(medgp_ctx *ctx, int slot, const double *theta, int nstar, const int32_t *meta2,
+                      const float *t2, float *mean, float *var, int32_t *status);
+
+/* block until all work queued on the context's stream is complete */
+int medgp_synchronize(medgp_ctx *ctx);
+
+/* ---- measurement hooks (bench.py roofline leg; no effect on results) ------------------------- */
+/* enable = 1: bracket every kernel launch with HIP events on the launch stream */
+int medgp_profile_enable(medgp_ctx *ctx, int enable);
+/* number of distinct kernels the library launches, and their names */
+int medgp_profile_num_kernels(void);
+const char *medgp_profile_kernel_name(int k);
+/* synchronises, then returns accumulated milliseconds and launch count of kernel k since the
+ * last medgp_profile_reset */
+int medgp_profile_read(medgp_ctx *ctx, int k, double *ms_total, int64_t *launches);
+int medgp_profile_reset(medgp_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,194 @@
+"""ctypes binding of libmedgp_hip.so (C ABI: include/medgp_hip.h).
+
+Mirrors the reference's call shape: a Context plays the role of the (kernel, likelihood,
+inference, prior) object set of main_one_train.cpp:103-152, `set_patient` of
+c_objective_one's constructor, `nlml_grad` of c_objective_one::compute_objective.
+Fails loudly when the HIP library is missing -- there is no CPU path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+KERNEL_SE, KERNEL_LMC_SM, KERNEL_SM = 0, 7, 8
+PRIOR_NONE, PRIOR_CLAMP, PRIOR_NORMAL, PRIOR_LAPLACE = -1, 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# every symbol include/medgp_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "medgp_abi_version", "medgp_device_count", "medgp_create", "medgp_destroy", "medgp_last_error",
+    "medgp_num_hyp", "medgp_set_pi", "medgp_set_stream", "medgp_reserve", "medgp_set_patient",
+    "medgp_set_prior", "medgp_nlml_grad", "medgp_nlml_grad_device", "medgp_get_factor",
+    "medgp_fit_predict", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
+    "medgp_profile_kernel_name", "medgp_profile_read", "medgp_profile_reset",
+]
+
+
+class MedgpError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmedgp_hip.so")
+
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise MedgpError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(make -C medgp_amd/csrc). medgp_amd has no CPU fallback.")
+    lib = C.CDLL(p)
+    vp, i32p, dp, fp, u8p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+    lib.medgp_abi_version.restype = C.c_int
+    lib.medgp_device_count.restype = C.c_int
+    lib.medgp_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.medgp_destroy.argtypes = [vp]
+    lib.medgp_destroy.restype = None
+    lib.medgp_last_error.argtypes = [vp]
+    lib.medgp_last_error.restype = C.c_char_p
+    lib.medgp_num_hyp.argtypes = [vp]
+    lib.medgp_set_pi.argtypes = [vp, C.c_double]
+    lib.medgp_set_stream.argtypes = [vp, vp]
+    lib.medgp_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.medgp_set_patient.argtypes = [vp, C.c_int, C.c_int, i32p, fp, fp]
+    lib.medgp_set_prior.argtypes = [vp, C.c_int, u8p, i32p, u8p, fp, fp]
+    lib.medgp_nlml_grad.argtypes = [vp, C.c_int, i32p, dp, C.c_int, dp, dp, i32p]
+    lib.medgp_nlml_grad_device.argtypes = [vp, C.c_int, i32p, vp, C.c_int, vp, vp, vp]
+    lib.medgp_get_factor.argtypes = [vp, C.c_int, fp, fp, fp]
+    lib.medgp_fit_predict.argtypes = [vp, C.c_int, dp, C.c_int, i32p, fp, fp, fp, i32p]
+    lib.medgp_synchronize.argtypes = [vp]
+    lib.medgp_profile_enable.argtypes = [vp, C.c_int]
+    lib.medgp_profile_num_kernels.restype = C.c_int
+    lib.medgp_profile_kernel_name.argtypes = [C.c_int]
+    lib.medgp_profile_kernel_name.restype = C.c_char_p
+    lib.medgp_profile_read.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64)]
+    lib.medgp_profile_reset.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def _ptr(a, ty):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+
+
+class Context:
+    """One (device, covariance family) evaluation context."""
+
+    def __init__(self, kernel_index=KERNEL_LMC_SM, Q=5, D=2, R=2, device=0):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.medgp_create(C.byref(h), int(device), int(kernel_index), int(Q), int(D), int(R))
+        if rc != 0:
+            raise MedgpError(f"medgp_create failed ({rc}): {self._lib.medgp_last_error(None).decode()}")
+        self._h = h
+        self.kernel_index, self.Q, self.D, self.R, self.device = kernel_index, Q, D, R, device
+        self.H = self._lib.medgp_num_hyp(h)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MedgpError(f"libmedgp_hip error {rc}: {self._lib.medgp_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.medgp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_pi(self, pi):
+        self._chk(self._lib.medgp_set_pi(self._h, float(pi)))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self._lib.medgp_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def reserve(self, max_slots, max_n, max_batch):
+        self._chk(self._lib.medgp_reserve(self._h, int(max_slots), int(max_n), int(max_batch)))
+
+    def set_patient(self, slot, meta, t, y):
+        t = np.ascontiguousarray(t, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        meta = None if meta is None else np.ascontiguousarray(meta, dtype=np.int32)
+        self._chk(self._lib.medgp_set_patient(self._h, int(slot), int(t.shape[0]), _ptr(meta, C.c_int32),
+                                              _ptr(t, C.c_float), _ptr(y, C.c_float)))
+
+    def set_prior(self, slot, flag=None, type=None, is_exp=None, p0=None, p1=None):
+        if flag is None:
+            self._chk(self._lib.medgp_set_prior(self._h, int(slot), None, None, None, None, None))
+            return
+        flag = np.ascontiguousarray(flag, dtype=np.uint8)
+        type = np.ascontiguousarray(type, dtype=np.int32)
+        is_exp = np.ascontiguousarray(is_exp, dtype=np.uint8)
+        p0 = np.ascontiguousarray(p0, dtype=np.float32)
+        p1 = np.ascontiguousarray(p1, dtype=np.float32)
+        assert flag.shape[0] == self.H
+        self._chk(self._lib.medgp_set_prior(self._h, int(slot), _ptr(flag, C.c_uint8), _ptr(type, C.c_int32),
+                                            _ptr(is_exp, C.c_uint8), _ptr(p0, C.c_float), _ptr(p1, C.c_float)))
+
+    def nlml_grad(self, slots, theta, flag_grad=True):
+        """Host-pointer operator. theta: [nbatch, H]. Returns (nlml[nbatch], grad[nbatch,H] or None, status[nbatch])."""
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(slots.shape[0], self.H)
+        nb = slots.shape[0]
+        nlml = np.empty(nb)
+        grad = np.empty((nb, self.H)) if flag_grad else None
+        status = np.empty(nb, dtype=np.int32)
+        self._chk(self._lib.medgp_nlml_grad(self._h, nb, _ptr(slots, C.c_int32), _ptr(theta, C.c_double),
+                                            int(bool(flag_grad)), _ptr(nlml, C.c_double), _ptr(grad, C.c_double),
+                                            _ptr(status, C.c_int32)))
+        return nlml, grad, status
+
+    def nlml_grad_device(self, slots, theta_ptr, flag_grad, nlml_ptr, grad_ptr, status_ptr):
+        """Device-pointer operator (asynchronous on the context's stream). Pointers are integers (tensor.data_ptr())."""
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        self._chk(self._lib.medgp_nlml_grad_device(self._h, slots.shape[0], _ptr(slots, C.c_int32), C.c_void_p(theta_ptr),
+                                                   int(bool(flag_grad)), C.c_void_p(nlml_ptr), C.c_void_p(grad_ptr or 0),
+                                                   C.c_void_p(status_ptr or 0)))
+
+    def get_factor(self, b, n, want_linv=True):
+        alpha = np.empty(n, dtype=np.float32)
+        linv = np.empty((n, n), dtype=np.float32) if want_linv else None
+        beta = C.c_float()
+        self._chk(self._lib.medgp_get_factor(self._h, int(b), _ptr(alpha, C.c_float), _ptr(linv, C.c_float), C.byref(beta)))
+        return alpha, linv, beta.value
+
+    def fit_predict(self, slot, theta, meta2, t2):
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        t2 = np.ascontiguousarray(t2, dtype=np.float32)
+        meta2 = None if meta2 is None else np.ascontiguousarray(meta2, dtype=np.int32)
+        ns = t2.shape[0]
+        mean = np.empty(ns, dtype=np.float32)
+        var = np.empty(ns, dtype=np.float32)
+        st = C.c_int32()
+        self._chk(self._lib.medgp_fit_predict(self._h, int(slot), _ptr(theta, C.c_double), ns, _ptr(meta2, C.c_int32),
+                                              _ptr(t2, C.c_float), _ptr(mean, C.c_float), _ptr(var, C.c_float), C.byref(st)))
+        return mean, var, st.value
+
+    def synchronize(self):
+        self._chk(self._lib.medgp_synchronize(self._h))
+
+    # measurement hooks
+    def profile_enable(self, on=True):
+        self._chk(self._lib.medgp_profile_enable(self._h, int(bool(on))))
+
+    def profile_reset(self):
+        self._chk(self._lib.medgp_profile_reset(self._h))
+
+    def profile_read(self):
+        out = {}
+        for k in range(self._lib.medgp_profile_num_kernels()):
+            ms, cnt = C.c_double(), C.c_int64()
+            self._chk(self._lib.medgp_profile_read(self._h, k, C.byref(ms), C.byref(cnt)))
+            out[self._lib.medgp_profile_kernel_name(k).decode()] = (ms.value, cnt.value)
+        return out

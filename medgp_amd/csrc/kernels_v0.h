@@ -1,0 +1,624 @@
+// kernels_v0.h -- first correct HIP statement of every stage (no MFMA, simple tiling).
+// These are the always-available baseline kernels; tuned gfx950 kernels (kernels_*.h)
+// replace them stage by stage and are checked against the same oracle.
+#pragma once
+#include "medgp_dev.h"
+
+// ------------------------------------------------------------------------------------------
+// stage 0: theta -> sigma^2, B_q, w_q = 2 pi mu_q, c_q = 2 (pi v_q)^2, cos/sin(w_q t_i) tables
+//   ref: c_kernel_LMC_SM.cpp:51-115 (exp transform, B_q), c_likelihood.cpp:38-43,
+//        c_kernel_SM.cpp:41-46, c_kernel_SE.cpp:47-52
+// The tables implement cos(w (t_i - t_j)) = cs_i cs_j + sn_i sn_j, so the N^2 pair loop needs no
+// trigonometric evaluation (c_kernel_LMC_SM.cpp:374-378 evaluates cos per pair).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restrict__ theta) {
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int slot = L.bslot[b];
+    const int n = L.pn[slot];
+    const double *th = theta + (size_t)b * L.H;
+    double *hyp = L.hyp + (size_t)b * L.hyp_stride;
+    double *sig2 = hyp, *B = hyp + hyp_off_B(L), *w = hyp + hyp_off_w(L), *c = hyp + hyp_off_c(L);
+    const int Q = L.Q, D = L.D, R = L.R;
+    const double pi = L.pi;
+    if (tid == 0) {
+        L.status[b] = (n > 2) ? 0 : -1;   // ref: util/c_objective_one.cpp:51
+        L.scal[b * 4 + 0] = 0.0;
+        L.scal[b * 4 + 1] = 0.0;
+    }
+    if (L.kidx == 7) {
+        for (int d = tid; d < D; d += nt) { double s = exp(th[d]); sig2[d] = s * s; }
+        const double *A = th + D, *lk = th + D + Q * (D * R + 2);
+        for (int idx = tid; idx < Q * D * D; idx += nt) {
+            int q = idx / (D * D), rem = idx - q * D * D, i = rem / D, j = rem - i * D;
+            const double *Ai = A + ((size_t)q * D + i) * R, *Aj = A + ((size_t)q * D + j) * R;
+            double s = 0.0;
+            for (int r = 0; r < R; r++) s += Ai[r] * Aj[r];
+            if (i == j) s += exp(lk[q * D + i]);
+            B[idx] = s;
+        }
+        for (int q = tid; q < Q; q += nt) {
+            double mu = exp(th[D + Q * D * R + q]), v = exp(th[D + Q * D * R + Q + q]);
+            double pv = pi * v;
+            w[q] = 2.0 * pi * mu;
+            c[q] = 2.0 * (pv * pv);
+        }
+    } else if (L.kidx == 8) {  // SM: theta = [log sigma | log w | log mu | log v]
+        if (tid == 0) { double s = exp(th[0]); sig2[0] = s * s; }
+        for (int q = tid; q < Q; q += nt) {
+            B[q] = exp(th[1 + q]);
+            double mu = exp(th[1 + Q + q]), v = exp(th[1 + 2 * Q + q]);
+            double pv = pi * v;
+            w[q] = 2.0 * pi * mu;
+            c[q] = 2.0 * (pv * pv);
+        }
+    } else {  // SE: theta = [log sigma | log l | log sf];  k = sf^2 exp(-d^2 / (2 l^2))
+        if (tid == 0) {
+            double s = exp(th[0]), l = exp(th[1]), sf = exp(th[2]);
+            sig2[0] = s * s;
+            B[0] = sf * sf;
+            w[0] = 0.0;
+            c[0] = 0.5 / (l * l);
+        }
+    }
+    __syncthreads();
+    const double *t = L.pt + (size_t)slot * L.ldn;
+    double *cs = L.cs + (size_t)b * Q * L.ldn, *sn = L.sn + (size_t)b * Q * L.ldn;
+    for (int idx = tid; idx < Q * L.ldn; idx += nt) {
+        int q = idx / L.ldn, i = idx - q * L.ldn;
+        double s = 0.0, co = 0.0;
+        if (i < n) sincos(w[q] * t[i], &s, &co);
+        cs[idx] = co;
+        sn[idx] = s;
+    }
+}
+
+// covariance of observations i, j of one problem (no noise)
+__device__ inline double cov_elem(const MedgpDev &L, const double *hyp, const double *cs, const double *sn,
+                                  const double *t, const int *meta, int i, int j) {
+    const int Q = L.Q, D = L.D;
+    const double *B = hyp + hyp_off_B(L), *c = hyp + hyp_off_c(L);
+    double d = t[i] - t[j], dd = d * d, acc = 0.0;
+    int bo = meta[i] * D + meta[j];
+    for (int q = 0; q < Q; q++) {
+        double E = exp(-c[q] * dd);
+        double cd = cs[q * L.ldn + i] * cs[q * L.ldn + j] + sn[q * L.ldn + i] * sn[q * L.ldn + j];
+        acc += B[q * D * D + bo] * (cd * E);
+    }
+    return acc;
+}
+
+__device__ inline void tile_decode(int x, int &I, int &J) {
+    int i = (int)((sqrt(8.0 * (double)x + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= x) i++;
+    while (i * (i + 1) / 2 > x) i--;
+    I = i;
+    J = x - i * (i + 1) / 2;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 1: Gram assembly, lower 64x64 tiles, noise on the diagonal, identity padding up to npad64
+//   ref: c_kernel_LMC_SM.cpp:152-196, c_inference_exact.cpp:88-92
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_assemble_v0(MedgpDev L) {
+    const int b = blockIdx.y;
+    if (L.status[b] < 0) return;
+    const int slot = L.bslot[b], n = L.pn[slot], npad = medgp_roundup(n, MEDGP_TILE), nt = npad / MEDGP_TILE;
+    int I, J;
+    tile_decode(blockIdx.x, I, J);
+    if (I >= nt) return;
+    const int ld = L.ldn;
+    const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
+    const double *cs = L.cs + (size_t)b * L.Q * ld, *sn = L.sn + (size_t)b * L.Q * ld;
+    const double *t = L.pt + (size_t)slot * ld;
+    const int *meta = L.pmeta + (size_t)slot * ld;
+    double *K = L.Kmat + (size_t)b * ld * ld;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    for (int a = 0; a < 4; a++)
+        for (int bb = 0; bb < 4; bb++) {
+            int i = I * 64 + ty + 16 * a, j = J * 64 + tx + 16 * bb;
+            double v;
+            if (i < n && j < n) {
+                v = cov_elem(L, hyp, cs, sn, t, meta, i, j);
+                if (i == j) v += hyp[meta[i]];
+            } else v = (i == j) ? 1.0 : 0.0;
+            K[(size_t)i * ld + j] = v;
+        }
+}
+
+// whole-matrix re-assembly by one workgroup with `count` extra noise additions (jitter path)
+//   ref: c_inference_exact.cpp:99-108
+__device__ void reassemble_wg(const MedgpDev &L, int b, int slot, int n, int np, int count) {
+    const int ld = L.ldn;
+    const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
+    const double *cs = L.cs + (size_t)b * L.Q * ld, *sn = L.sn + (size_t)b * L.Q * ld;
+    const double *t = L.pt + (size_t)slot * ld;
+    const int *meta = L.pmeta + (size_t)slot * ld;
+    double *K = L.Kmat + (size_t)b * ld * ld;
+    for (int idx = threadIdx.x; idx < np * np; idx += blockDim.x) {
+        int i = idx / np, j = idx - i * np;
+        if (j > i) continue;
+        double v;
+        if (i < n && j < n) {
+            v = cov_elem(L, hyp, cs, sn, t, meta, i, j);
+            if (i == j) {
+                double lik = hyp[meta[i]];
+                v += lik;
+                for (int r = 0; r < count; r++) v += lik;
+            }
+        } else v = (i == j) ? 1.0 : 0.0;
+        K[(size_t)i * ld + j] = v;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 2: Cholesky (lower, in place) + forward solve z = L^-1 y + log-det + quad, with the
+// reference's jitter-retry loop.  Right-looking, 16-wide panels, one workgroup per problem.
+//   ref: c_inference_exact.cpp:96-125, 146   (LAPACKE_spotrf / spotrs live in MKL)
+// ------------------------------------------------------------------------------------------
+struct PotrfSmem {
+    double Akk[16][17];
+    double Pi[64][17];
+    double Pj[64][17];
+    double zb[16];
+    double red[256];
+    double logdet;
+    int fail;
+};
+
+__device__ bool potrf_wg_v0(double *A, int ld, int np, double *zz, PotrfSmem &sm) {
+    const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
+    if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
+    __syncthreads();
+    for (int k0 = 0; k0 < np; k0 += 16) {
+        sm.Akk[r][c] = A[(size_t)(k0 + r) * ld + k0 + c];
+        __syncthreads();
+        for (int j = 0; j < 16; j++) {
+            if (tid == 0) {
+                double piv = sm.Akk[j][j];
+                if (!(piv > 0.0)) sm.fail = 1;   // LAPACK potf2: ajj <= 0 or NaN
+                else { piv = sqrt(piv); sm.Akk[j][j] = piv; sm.logdet += log(piv); }
+            }
+            __syncthreads();
+            if (sm.fail) return false;
+            if (c == j && r > j) sm.Akk[r][j] /= sm.Akk[j][j];
+            __syncthreads();
+            if (c > j && r >= c) sm.Akk[r][c] -= sm.Akk[r][j] * sm.Akk[c][j];
+            __syncthreads();
+        }
+        if (r >= c) A[(size_t)(k0 + r) * ld + k0 + c] = sm.Akk[r][c];
+        // z block: L_kk z_k = y_k (already updated by previous panels)
+        if (tid == 0) {
+            for (int rr = 0; rr < 16; rr++) {
+                double s = zz[k0 + rr];
+                for (int cc = 0; cc < rr; cc++) s -= sm.Akk[rr][cc] * sm.zb[cc];
+                s /= sm.Akk[rr][rr];
+                sm.zb[rr] = s;
+                zz[k0 + rr] = s;
+            }
+        }
+        __syncthreads();
+        // panel: rows below solve x L_kk^T = a; update z
+        for (int i = k0 + 16 + tid; i < np; i += blockDim.x) {
+            double x[16];
+            double *ai = A + (size_t)i * ld + k0;
+            double zacc = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) x[cc] = ai[cc];
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) {
+                double s = x[cc];
+#pragma unroll
+                for (int c2 = 0; c2 < cc; c2++) s -= x[c2] * sm.Akk[cc][c2];
+                s /= sm.Akk[cc][cc];
+                x[cc] = s;
+                zacc += s * sm.zb[cc];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) ai[cc] = x[cc];
+            zz[i] -= zacc;
+        }
+        __syncthreads();
+        // trailing update, 64x64 tiles of rows/cols >= k0+16
+        const int m0 = k0 + 16, mt = (np - m0 + 63) / 64;
+        for (int ti = 0; ti < mt; ti++)
+            for (int tj = 0; tj <= ti; tj++) {
+                const int I0 = m0 + ti * 64, J0 = m0 + tj * 64;
+                {
+                    int rr = tid >> 2, c4 = (tid & 3) * 4;
+                    int gi = I0 + rr, gj = J0 + rr;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        sm.Pi[rr][c4 + u] = (gi < np) ? A[(size_t)gi * ld + k0 + c4 + u] : 0.0;
+                        sm.Pj[rr][c4 + u] = (gj < np) ? A[(size_t)gj * ld + k0 + c4 + u] : 0.0;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int bb = 0; bb < 4; bb++) {
+                        int li = r + 16 * a, lj = c + 16 * bb;
+                        int i = I0 + li, j = J0 + lj;
+                        if (i < np && j <= i) {
+                            double s = 0.0;
+#pragma unroll
+                            for (int cc = 0; cc < 16; cc++) s += sm.Pi[li][cc] * sm.Pj[lj][cc];
+                            A[(size_t)i * ld + j] -= s;
+                        }
+                    }
+                __syncthreads();
+            }
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_potrf_v0(MedgpDev L) {
+    __shared__ PotrfSmem sm;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (L.status[b] < 0) return;
+    const int slot = L.bslot[b], n = L.pn[slot], np = medgp_roundup(n, 16), ld = L.ldn;
+    double *A = L.Kmat + (size_t)b * ld * ld;
+    double *zz = L.z + (size_t)b * ld;
+    const double *y = L.py + (size_t)slot * ld;
+    int count = 0;
+    while (true) {
+        for (int i = tid; i < ld; i += blockDim.x) zz[i] = (i < n) ? y[i] : 0.0;
+        __syncthreads();
+        if (potrf_wg_v0(A, ld, np, zz, sm)) break;
+        __syncthreads();
+        if (count >= 10) {   // ref: c_inference_exact.cpp:99,109-111
+            if (tid == 0) L.status[b] = -1;
+            return;
+        }
+        count++;
+        reassemble_wg(L, b, slot, n, np, count);
+    }
+    // quad = z^T z, deterministic tree
+    double s = 0.0;
+    for (int i = tid; i < np; i += blockDim.x) s += zz[i] * zz[i];
+    sm.red[tid] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) sm.red[tid] += sm.red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        L.status[b] = count;
+        L.scal[b * 4 + 0] = sm.logdet;
+        L.scal[b * 4 + 1] = sm.red[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 3: X = L^-1 (lower) by forward substitution, one thread per column; alpha = X^T z.
+//   ref: c_inference_exact.cpp:124-143 (spotrs, strtri)
+// Rows/cols in [np16, npad64) are identity padding.  Entries above the diagonal are NOT written
+// (consumers mask k < i).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_trtri_v0(MedgpDev L) {
+    const int b = blockIdx.x;
+    if (L.status[b] < 0) return;
+    const int slot = L.bslot[b], n = L.pn[slot], np = medgp_roundup(n, 16), npad = medgp_roundup(n, 64), ld = L.ldn;
+    const double *Lm = L.Kmat + (size_t)b * ld * ld;
+    double *X = L.Linv + (size_t)b * ld * ld;
+    const double *zz = L.z + (size_t)b * ld;
+    double *alpha = L.alpha + (size_t)b * ld;
+    const int lane = threadIdx.x & 63;
+    for (int j = threadIdx.x; j < npad; j += blockDim.x) {
+        const int jw = j - lane;   // first column of this wave (uniform)
+        if (jw >= np) {            // whole wave in the identity padding
+            for (int i = j; i < npad; i++) X[(size_t)i * ld + j] = (i == j) ? 1.0 : 0.0;
+            alpha[j] = 0.0;
+            continue;
+        }
+        const bool real = j < np;
+        if (real) X[(size_t)j * ld + j] = 1.0 / Lm[(size_t)j * ld + j];
+        for (int i = jw + 1; i < np; i++) {
+            double s = 0.0;
+            const double *li = Lm + (size_t)i * ld;
+            for (int k = jw; k < i; k++) {
+                double xv = (real && k >= j) ? X[(size_t)k * ld + j] : 0.0;
+                s += li[k] * xv;
+            }
+            if (real && i > j) X[(size_t)i * ld + j] = -s / li[i];
+        }
+        if (real) {
+            for (int i = np; i < npad; i++) X[(size_t)i * ld + j] = 0.0;
+            double a = 0.0;
+            for (int i = j; i < np; i++) a += X[(size_t)i * ld + j] * zz[i];
+            alpha[j] = a;
+        } else {
+            for (int i = j; i < npad; i++) X[(size_t)i * ld + j] = (i == j) ? 1.0 : 0.0;
+            alpha[j] = 0.0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 4: W = L^-T L^-1 - alpha alpha^T, lower 64x64 tiles, written over the (dead) L buffer
+//   ref: c_inference_exact.cpp:168-172
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lauum_v0(MedgpDev L) {
+    __shared__ double Ai[16][64], Aj[16][64];
+    const int b = blockIdx.y;
+    if (L.status[b] < 0) return;
+    const int slot = L.bslot[b], n = L.pn[slot], np = medgp_roundup(n, 16), nt = medgp_roundup(n, 64) / 64, ld = L.ldn;
+    int I, J;
+    tile_decode(blockIdx.x, I, J);
+    if (I >= nt) return;
+    const double *X = L.Linv + (size_t)b * ld * ld;
+    const double *alpha = L.alpha + (size_t)b * ld;
+    double *W = L.Kmat + (size_t)b * ld * ld;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int i0 = I * 64, j0 = J * 64;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) acc[a][bb] = 0.0;
+    for (int kc = i0; kc < np; kc += 16) {
+        {
+            int kk = tid >> 4, c4 = (tid & 15) * 4, k = kc + kk;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int ii = i0 + c4 + u, jj = j0 + c4 + u;
+                Ai[kk][c4 + u] = (k < np && k >= ii) ? X[(size_t)k * ld + ii] : 0.0;
+                Aj[kk][c4 + u] = (k < np && k >= jj) ? X[(size_t)k * ld + jj] : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++)
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) acc[a][bb] += Ai[kk][ty + 16 * a] * Aj[kk][tx + 16 * bb];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) {
+            int i = i0 + ty + 16 * a, j = j0 + tx + 16 * bb;
+            W[(size_t)i * ld + j] = acc[a][bb] - alpha[i] * alpha[j];
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 5: block reductions over the lower triangle of W (observations are grouped by output):
+//   S_q[d,e]  = sum_{i in d, j in e} W_ij k_q(ij)
+//   SM_q[d,e] = sum W_ij * ( -(w d) sin(w d) E )          (d k_q / d log mu_q)
+//   SV_q[d,e] = sum W_ij * ( -2 c d^2 k_q )               (d k_q / d log v_q)
+// for e <= d; diagonal blocks count off-diagonal pairs twice.  One thread per (q, d, e): fixed
+// summation order => bitwise reproducible.
+//   ref: c_kernel_LMC_SM.cpp:198-327 regrouped; k/km/kv :374-391
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gradbins_v0(MedgpDev L) {
+    const int b = blockIdx.y;
+    if (L.status[b] < 0) return;
+    const int Q = L.Q, D = L.D, nb = D * (D + 1) / 2, ld = L.ldn;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Q * nb) return;
+    const int q = idx / nb;
+    int d, e;
+    tile_decode(idx - q * nb, d, e);
+    const int slot = L.bslot[b];
+    const int *seg = L.pseg + (size_t)slot * (D + 1);
+    const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
+    const double wq = hyp[hyp_off_w(L) + q], cq = hyp[hyp_off_c(L) + q];
+    const double *cs = L.cs + ((size_t)b * Q + q) * ld, *sn = L.sn + ((size_t)b * Q + q) * ld;
+    const double *t = L.pt + (size_t)slot * ld;
+    const double *W = L.Kmat + (size_t)b * ld * ld;
+    const int r0 = seg[d], r1 = seg[d + 1], c0 = seg[e], c1 = seg[e + 1];
+    double aS = 0.0, aM = 0.0, aV = 0.0;
+    for (int i = r0; i < r1; i++) {
+        const double ti = t[i], ci = cs[i], si = sn[i];
+        const int jend = (d == e) ? i + 1 : c1;
+        for (int j = c0; j < jend; j++) {
+            double wv = W[(size_t)i * ld + j];
+            if (d == e && j < i) wv *= 2.0;
+            double dt = ti - t[j], dd = dt * dt;
+            double E = exp(-cq * dd);
+            double cd = ci * cs[j] + si * sn[j];
+            double sd = si * cs[j] - ci * sn[j];
+            double k = cd * E;
+            double wd = wq * dt;
+            aS += wv * k;
+            aM += wv * (-(wd * sd) * E);
+            aV += wv * (-2.0 * cq * dd * k);
+        }
+    }
+    const size_t o = (size_t)b * Q * D * D + (size_t)q * D * D + d * D + e;
+    L.S[o] = aS;
+    L.SM[o] = aM;
+    L.SV[o] = aV;
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 6: gradient in theta order + priors + nlml
+//   ref: c_inference_exact.cpp:146-152 (nlml), :177-219 (order), c_inference_prior.cpp:60-150,
+//        prior/c_prior.cpp:383-421
+// ------------------------------------------------------------------------------------------
+__device__ inline void prior_apply(const MedgpPrior &p, double hv, double pi, bool want_grad, double &lp_sum, double &g) {
+    if (!p.flag) return;
+    if (p.type == 0) { if (want_grad) g = 0.0; return; }
+    double lp, dlp;
+    if (p.type == 1) {
+        lp = -1.0 * (hv - p.p0) * (hv - p.p0) / (2.0 * p.p1);
+        lp = lp - log(2 * pi * p.p1) / 2.0;
+        dlp = -1.0 * (hv - p.p0) / p.p1;
+    } else if (p.type == 2) {
+        lp = (-1.0 * fabs(hv - p.p0) / p.p1) - log((double)(2 * p.p1));
+        if (hv == p.p0) dlp = 0.0;
+        else dlp = -1.0 * ((hv > p.p0) ? 1.0 : -1.0) / p.p1;
+    } else return;
+    lp_sum += lp;
+    if (want_grad) g -= p.is_exp ? hv * dlp : dlp;
+}
+
+__device__ inline double sym_get(const double *S, int D, int d, int e) { return d >= e ? S[d * D + e] : S[e * D + d]; }
+
+__global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__restrict__ theta, int flag_grad,
+                                                  double *__restrict__ nlml_out, double *__restrict__ grad_out,
+                                                  int *__restrict__ status_out) {
+    __shared__ double red[256];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int H = L.H, Q = L.Q, D = L.D, R = L.R, ld = L.ldn;
+    const int st = L.status[b];
+    double *g = grad_out ? grad_out + (size_t)b * H : nullptr;
+    if (tid == 0 && status_out) status_out[b] = st;
+    if (st < 0) {
+        if (tid == 0) nlml_out[b] = __builtin_nan("");
+        if (flag_grad && g) for (int h = tid; h < H; h += nt) g[h] = __builtin_nan("");
+        return;
+    }
+    const int slot = L.bslot[b], n = L.pn[slot];
+    const double *th = theta + (size_t)b * H;
+    const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
+    const double *B = hyp + hyp_off_B(L);
+    const double *S = L.S + (size_t)b * Q * D * D, *SM = L.SM + (size_t)b * Q * D * D, *SV = L.SV + (size_t)b * Q * D * D;
+    const int *seg = L.pseg + (size_t)slot * (D + 1);
+    const double *W = L.Kmat + (size_t)b * ld * ld;
+    const MedgpPrior *pr = L.prior_on[slot] ? L.prior + (size_t)slot * H : nullptr;
+    double lp_local = 0.0;
+    for (int h = tid; h < H; h += nt) {
+        double gv = 0.0, hv;   // hv = transformed hyper value (what the prior is evaluated at)
+        if (L.kidx == 7) {
+            if (h < D) {
+                hv = exp(th[h]);
+                if (flag_grad) {
+                    double s = 0.0;
+                    for (int i = seg[h]; i < seg[h + 1]; i++) s += hv * hv * W[(size_t)i * ld + i];
+                    gv = s;   // ref: c_inference_exact.cpp:194-202
+                }
+            } else {
+                int hc = h - D;
+                if (hc < Q * D * R) {
+                    hv = th[h];
+                    if (flag_grad) {
+                        int q = hc / (D * R), rem = hc - q * D * R, d = rem / R, r = rem - d * R;
+                        const double *A = th + D + (size_t)q * D * R;
+                        const double *Sq = S + (size_t)q * D * D;
+                        double s = 0.0;
+                        for (int e = 0; e < D; e++) s += sym_get(Sq, D, d, e) * A[e * R + r];
+                        gv = s;
+                    }
+                } else if (hc < Q * (D * R + 2)) {
+                    hv = exp(th[h]);
+                    if (flag_grad) {
+                        bool is_mu = hc < Q * (D * R + 1);
+                        int q = is_mu ? hc - Q * D * R : hc - Q * (D * R + 1);
+                        const double *X = (is_mu ? SM : SV) + (size_t)q * D * D, *Bq = B + (size_t)q * D * D;
+                        double s = 0.0;
+                        for (int d = 0; d < D; d++)
+                            for (int e = 0; e <= d; e++) s += ((d == e) ? 1.0 : 2.0) * Bq[d * D + e] * X[d * D + e];
+                        gv = 0.5 * s;
+                    }
+                } else {
+                    hv = exp(th[h]);
+                    if (flag_grad) {
+                        int kk = hc - Q * (D * R + 2), q = kk / D, d = kk - q * D;
+                        gv = 0.5 * hv * S[(size_t)q * D * D + d * D + d];
+                    }
+                }
+            }
+        } else if (L.kidx == 8) {   // SM: [log sigma | log w | log mu | log v]; blocks are 1x1
+            hv = exp(th[h]);
+            if (flag_grad) {
+                if (h == 0) {
+                    double s = 0.0;
+                    for (int i = 0; i < n; i++) s += hv * hv * W[(size_t)i * ld + i];
+                    gv = s;
+                } else {
+                    int hc = h - 1, mode = hc / Q, q = hc - mode * Q;
+                    const double *X = mode == 0 ? S : (mode == 1 ? SM : SV);
+                    gv = 0.5 * B[q] * X[q];
+                }
+            }
+        } else {                     // SE: [log sigma | log l | log sf]
+            hv = exp(th[h]);
+            if (flag_grad) {
+                if (h == 0) {
+                    double s = 0.0;
+                    for (int i = 0; i < n; i++) s += hv * hv * W[(size_t)i * ld + i];
+                    gv = s;
+                } else if (h == 1) gv = -0.5 * B[0] * SV[0];   // d/dlog l = -d/dlog v  (ref: c_kernel_SE.cpp:106-118)
+                else gv = B[0] * S[0];                         // ref: c_kernel_SE.cpp:120-131
+            }
+        }
+        if (pr) prior_apply(pr[h], hv, L.pi, flag_grad != 0, lp_local, gv);
+        if (flag_grad && g) g[h] = gv;
+    }
+    // deterministic reduction of the prior log-density
+    red[tid] = lp_local;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double logdet = L.scal[b * 4 + 0], quad = L.scal[b * 4 + 1];
+        double nlml = quad / 2.0 + logdet + n * log(2. * L.pi) / 2.0;   // ref: c_inference_exact.cpp:149-152
+        nlml_out[b] = nlml - red[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// predict: one workgroup per test point.  mean = k*^T alpha; var = k** - |L^-1 k*|^2 + sigma^2
+//   ref: core/gp_regression.cpp:128-214, c_kernel_LMC_SM.cpp:329-372, :122-150
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_predict_v0(MedgpDev L, int b, int nstar, const int *__restrict__ meta2,
+                                                   const double *__restrict__ t2, double *__restrict__ ks_buf,
+                                                   float *__restrict__ mean, float *__restrict__ var) {
+    __shared__ double red[256];
+    const int js = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, Q = L.Q, D = L.D;
+    if (L.status[b] < 0) {
+        if (tid == 0) { mean[js] = __builtin_nanf(""); var[js] = __builtin_nanf(""); }
+        return;
+    }
+    const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
+    const double *B = hyp + hyp_off_B(L), *w = hyp + hyp_off_w(L), *c = hyp + hyp_off_c(L);
+    const double *t = L.pt + (size_t)slot * ld;
+    const int *meta = L.pmeta + (size_t)slot * ld;
+    const double *alpha = L.alpha + (size_t)b * ld;
+    const double *X = L.Linv + (size_t)b * ld * ld;
+    double *ks = ks_buf + (size_t)js * ld;
+    const int ms = meta2 ? meta2[js] : 0;
+    const double ts = t2[js];
+    double m = 0.0;
+    for (int i = tid; i < n; i += nt) {
+        double d = t[i] - ts, dd = d * d, acc = 0.0;
+        for (int q = 0; q < Q; q++) acc += B[q * D * D + meta[i] * D + ms] * (cos(w[q] * d) * exp(-c[q] * dd));
+        ks[i] = acc;
+        m += acc * alpha[i];
+    }
+    red[tid] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    const double mval = red[0];
+    __syncthreads();
+    double qv = 0.0;
+    for (int i = tid; i < n; i += nt) {
+        double s = 0.0;
+        const double *xi = X + (size_t)i * ld;
+        for (int k = 0; k <= i; k++) s += xi[k] * ks[k];
+        qv += s * s;
+    }
+    red[tid] = qv;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double kss = 0.0;
+        for (int q = 0; q < Q; q++) kss += B[q * D * D + ms * D + ms];
+        mean[js] = (float)mval;
+        var[js] = (float)(kss - red[0] + hyp[ms]);
+    }
+}

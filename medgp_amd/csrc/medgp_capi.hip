@@ -1,0 +1,517 @@
+// medgp_capi.hip -- C ABI of libmedgp_hip.so (see include/medgp_hip.h) and the launch pipeline.
+// gfx950 only; there is deliberately no CPU fallback: without a HIP device every compute entry
+// point fails with MEDGP_ERR_NODEVICE.
+#include "../../include/medgp_hip.h"
+#include "medgp_dev.h"
+#include "kernels_v0.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+enum KernelId { KID_PREP = 0, KID_ASSEMBLE, KID_POTRF, KID_TRTRI, KID_LAUUM, KID_GRADBINS, KID_EPILOGUE, KID_PREDICT, KID_COUNT };
+const char *const kKernelNames[KID_COUNT] = {"k_prep", "k_assemble", "k_potrf", "k_trtri", "k_lauum", "k_gradbins", "k_epilogue", "k_predict"};
+
+std::string g_create_error;
+
+struct EvPair { int kid; hipEvent_t a, b; };
+
+}  // namespace
+
+struct medgp_ctx {
+    int device = -1;
+    int kidx = 0, Q = 0, D = 0, R = 0, H = 0, nlik = 0;
+    double pi = 3.14159265;   // ref: util/global_settings.h:6
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int max_slots = 0, max_n = 0, max_batch = 0, ldn = 0;
+    MedgpDev dev{};
+    // device allocations
+    std::vector<void *> allocs;
+    int *d_pn = nullptr, *d_pmeta = nullptr, *d_pseg = nullptr, *d_bslot = nullptr, *d_status = nullptr;
+    double *d_pt = nullptr, *d_py = nullptr;
+    MedgpPrior *d_prior = nullptr;
+    uint8_t *d_prior_on = nullptr;
+    double *d_theta = nullptr, *d_nlml = nullptr, *d_grad = nullptr;   // staging for the host-pointer API
+    int *d_status_out = nullptr;
+    // host mirrors
+    std::vector<int> h_n;
+    std::vector<std::vector<int>> h_perm;   // internal index -> caller index
+    std::vector<uint8_t> h_perm_identity;
+    std::vector<int> h_bslot;
+    int last_nbatch = 0;
+    // predict scratch
+    double *d_t2 = nullptr, *d_ks = nullptr;
+    int *d_meta2 = nullptr;
+    float *d_mean = nullptr, *d_var = nullptr;
+    int pred_cap = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<EvPair> events;
+    double prof_ms[KID_COUNT] = {0};
+    int64_t prof_n[KID_COUNT] = {0};
+    std::string err;
+};
+
+namespace {
+
+int fail(medgp_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) return fail((c), MEDGP_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int dalloc(medgp_ctx *c, T **p, size_t count) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) return fail(c, MEDGP_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    c->allocs.push_back(q);
+    *p = (T *)q;
+    return MEDGP_OK;
+}
+
+void free_all(medgp_ctx *c) {
+    for (void *p : c->allocs) (void)hipFree(p);
+    c->allocs.clear();
+}
+
+int num_cov(int kidx, int Q, int D, int R) {
+    switch (kidx) {
+    case MEDGP_KERNEL_LMC_SM: return Q * (D * R + 2 + D);
+    case MEDGP_KERNEL_SM: return 3 * Q;
+    case MEDGP_KERNEL_SE: return 2;
+    default: return -1;
+    }
+}
+
+struct Launcher {
+    medgp_ctx *c;
+    int kid;
+    hipEvent_t a = nullptr, b = nullptr;
+    Launcher(medgp_ctx *c_, int kid_) : c(c_), kid(kid_) {
+        if (c->profiling) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~Launcher() {
+        if (c->profiling) {
+            (void)hipEventRecord(b, c->stream);
+            c->events.push_back({kid, a, b});
+        }
+    }
+};
+
+int drain_events(medgp_ctx *c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto &e : c->events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->prof_ms[e.kid] += ms;
+            c->prof_n[e.kid] += 1;
+        }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    c->events.clear();
+    return MEDGP_OK;
+}
+
+int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out) {
+    if (nbatch < 1 || nbatch > c->max_batch) return fail(c, MEDGP_ERR_CAPACITY, "nbatch %d outside [1, %d]", nbatch, c->max_batch);
+    int mx = 0;
+    for (int b = 0; b < nbatch; b++) {
+        int s = slots[b];
+        if (s < 0 || s >= c->max_slots || c->h_n[s] < 0) return fail(c, MEDGP_ERR_ARG, "slots[%d] = %d is not a resident patient", b, s);
+        mx = std::max(mx, c->h_n[s]);
+    }
+    *max_n_out = mx;
+    bool same = (nbatch == c->last_nbatch) && std::memcmp(c->h_bslot.data(), slots, sizeof(int) * nbatch) == 0;
+    if (!same) {
+        std::memcpy(c->h_bslot.data(), slots, sizeof(int) * nbatch);
+        HIPCHK(c, hipMemcpyAsync(c->d_bslot, c->h_bslot.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // h_bslot may be rewritten by the next call
+        c->last_nbatch = nbatch;
+    }
+    return MEDGP_OK;
+}
+
+inline int tri(int n) { return n * (n + 1) / 2; }
+
+// the evaluation pipeline; everything is asynchronous on c->stream
+int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, int flag_grad, bool need_inverse,
+                 double *nlml_dev, double *grad_dev, int32_t *status_dev) {
+    const MedgpDev &L = c->dev;
+    const int nt64 = medgp_roundup(std::max(max_n, 1), 64) / 64;
+    { Launcher l(c, KID_PREP); hipLaunchKernelGGL(k_prep, dim3(nbatch), dim3(256), 0, c->stream, L, theta_dev); }
+    { Launcher l(c, KID_ASSEMBLE); hipLaunchKernelGGL(k_assemble_v0, dim3(tri(nt64), nbatch), dim3(256), 0, c->stream, L); }
+    { Launcher l(c, KID_POTRF); hipLaunchKernelGGL(k_potrf_v0, dim3(nbatch), dim3(256), 0, c->stream, L); }
+    if (flag_grad || need_inverse) {
+        { Launcher l(c, KID_TRTRI); hipLaunchKernelGGL(k_trtri_v0, dim3(nbatch), dim3(256), 0, c->stream, L); }
+    }
+    if (flag_grad) {
+        { Launcher l(c, KID_LAUUM); hipLaunchKernelGGL(k_lauum_v0, dim3(tri(nt64), nbatch), dim3(256), 0, c->stream, L); }
+        const int nbins = L.Q * tri(L.D);
+        { Launcher l(c, KID_GRADBINS); hipLaunchKernelGGL(k_gradbins_v0, dim3((nbins + 255) / 256, nbatch), dim3(256), 0, c->stream, L); }
+    }
+    if (nlml_dev) {
+        Launcher l(c, KID_EPILOGUE);
+        hipLaunchKernelGGL(k_epilogue, dim3(nbatch), dim3(256), 0, c->stream, L, theta_dev, flag_grad, nlml_dev, grad_dev, (int *)status_dev);
+    }
+    HIPCHK(c, hipGetLastError());
+    return MEDGP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int medgp_abi_version(void) { return 1; }
+
+int medgp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *medgp_last_error(const medgp_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, int R) {
+    if (!out) return fail(nullptr, MEDGP_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (kernel_index == MEDGP_KERNEL_SE) { Q = 1; D = 1; R = 0; }
+    if (kernel_index == MEDGP_KERNEL_SM) { D = 1; R = 0; }
+    int nc = num_cov(kernel_index, Q, D, R);
+    if (nc < 0) return fail(nullptr, MEDGP_ERR_ARG, "unsupported kernel_index %d (supported: 0 SE, 7 LMC-SM, 8 SM)", kernel_index);
+    if (Q < 1 || D < 1 || R < 0) return fail(nullptr, MEDGP_ERR_ARG, "bad Q/D/R = %d/%d/%d", Q, D, R);
+    int ndev = medgp_device_count();
+    if (ndev <= 0) return fail(nullptr, MEDGP_ERR_NODEVICE, "no HIP device visible; libmedgp_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, MEDGP_ERR_ARG, "device %d outside [0, %d)", device, ndev);
+    medgp_ctx *c = new medgp_ctx();
+    c->device = device;
+    c->kidx = kernel_index; c->Q = Q; c->D = D; c->R = R;
+    c->nlik = (kernel_index == MEDGP_KERNEL_LMC_SM) ? D : 1;
+    c->H = c->nlik + nc;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(nullptr, MEDGP_ERR_HIP, "cannot initialise device %d", device);
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return MEDGP_OK;
+}
+
+void medgp_destroy(medgp_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    free_all(c);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int medgp_num_hyp(const medgp_ctx *c) { return c ? c->H : MEDGP_ERR_ARG; }
+
+int medgp_set_pi(medgp_ctx *c, double pi) {
+    if (!c || !(pi > 0)) return MEDGP_ERR_ARG;
+    c->pi = pi;
+    c->dev.pi = pi;
+    return MEDGP_OK;
+}
+
+int medgp_set_stream(medgp_ctx *c, void *s) {
+    if (!c) return MEDGP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return MEDGP_OK;
+}
+
+int medgp_synchronize(medgp_ctx *c) {
+    if (!c) return MEDGP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MEDGP_OK;
+}
+
+int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (max_slots < 1 || max_n < 1 || max_batch < 1) return fail(c, MEDGP_ERR_ARG, "medgp_reserve: non-positive capacity");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_all(c);
+    c->max_slots = max_slots; c->max_n = max_n; c->max_batch = max_batch;
+    const int ldn = medgp_roundup(max_n, 64);
+    c->ldn = ldn;
+    const size_t S = max_slots, B = max_batch, Q = c->Q, D = c->D, H = c->H;
+    int rc;
+    if ((rc = dalloc(c, &c->d_pn, S))) return rc;
+    if ((rc = dalloc(c, &c->d_pt, S * ldn))) return rc;
+    if ((rc = dalloc(c, &c->d_py, S * ldn))) return rc;
+    if ((rc = dalloc(c, &c->d_pmeta, S * ldn))) return rc;
+    if ((rc = dalloc(c, &c->d_pseg, S * (D + 1)))) return rc;
+    if ((rc = dalloc(c, &c->d_prior, S * H))) return rc;
+    if ((rc = dalloc(c, &c->d_prior_on, S))) return rc;
+    if ((rc = dalloc(c, &c->d_bslot, B))) return rc;
+    if ((rc = dalloc(c, &c->d_status, B))) return rc;
+    if ((rc = dalloc(c, &c->d_theta, B * H))) return rc;
+    if ((rc = dalloc(c, &c->d_nlml, B))) return rc;
+    if ((rc = dalloc(c, &c->d_grad, B * H))) return rc;
+    if ((rc = dalloc(c, &c->d_status_out, B))) return rc;
+    MedgpDev &L = c->dev;
+    L.kidx = c->kidx; L.Q = c->Q; L.D = c->D; L.R = c->R; L.H = c->H; L.nlik = c->nlik;
+    L.ldn = ldn; L.max_slots = max_slots; L.max_batch = max_batch;
+    L.hyp_stride = (int)(D + Q * D * D + 2 * Q);
+    L.pi = c->pi;
+    double *hyp, *cs, *sn, *Kmat, *Linv, *z, *alpha, *scal, *Sb, *SMb, *SVb;
+    if ((rc = dalloc(c, &hyp, B * L.hyp_stride))) return rc;
+    if ((rc = dalloc(c, &cs, B * Q * ldn))) return rc;
+    if ((rc = dalloc(c, &sn, B * Q * ldn))) return rc;
+    if ((rc = dalloc(c, &Kmat, B * ldn * ldn))) return rc;
+    if ((rc = dalloc(c, &Linv, B * ldn * ldn))) return rc;
+    if ((rc = dalloc(c, &z, B * ldn))) return rc;
+    if ((rc = dalloc(c, &alpha, B * ldn))) return rc;
+    if ((rc = dalloc(c, &scal, B * 4))) return rc;
+    if ((rc = dalloc(c, &Sb, B * Q * D * D))) return rc;
+    if ((rc = dalloc(c, &SMb, B * Q * D * D))) return rc;
+    if ((rc = dalloc(c, &SVb, B * Q * D * D))) return rc;
+    L.pn = c->d_pn; L.pt = c->d_pt; L.py = c->d_py; L.pmeta = c->d_pmeta; L.pseg = c->d_pseg;
+    L.prior = c->d_prior; L.prior_on = c->d_prior_on; L.bslot = c->d_bslot;
+    L.hyp = hyp; L.cs = cs; L.sn = sn; L.Kmat = Kmat; L.Linv = Linv; L.z = z; L.alpha = alpha; L.scal = scal;
+    L.status = c->d_status; L.S = Sb; L.SM = SMb; L.SV = SVb;
+    HIPCHK(c, hipMemsetAsync(c->d_prior_on, 0, S, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_pn, 0, S * sizeof(int), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->h_n.assign(max_slots, -1);
+    c->h_perm.assign(max_slots, {});
+    c->h_perm_identity.assign(max_slots, 1);
+    c->h_bslot.assign(max_batch, -1);
+    c->last_nbatch = 0;
+    c->pred_cap = 0;
+    return MEDGP_OK;
+}
+
+int medgp_set_patient(medgp_ctx *c, int slot, int n, const int32_t *meta, const float *t, const float *y) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
+    if (slot < 0 || slot >= c->max_slots) return fail(c, MEDGP_ERR_CAPACITY, "slot %d outside [0, %d)", slot, c->max_slots);
+    if (n < 0 || n > c->max_n) return fail(c, MEDGP_ERR_CAPACITY, "n = %d outside [0, %d]", n, c->max_n);
+    if (n > 0 && (!t || !y)) return fail(c, MEDGP_ERR_ARG, "t / y is NULL");
+    const int D = c->D, ldn = c->ldn;
+    const bool use_meta = (c->kidx == MEDGP_KERNEL_LMC_SM);
+    if (use_meta && n > 0 && !meta) return fail(c, MEDGP_ERR_ARG, "meta is NULL for the multi-output kernel");
+    // stable grouping by output (counting sort)
+    std::vector<int> seg(D + 1, 0), perm(n);
+    if (use_meta) {
+        for (int i = 0; i < n; i++) {
+            if (meta[i] < 0 || meta[i] >= D) return fail(c, MEDGP_ERR_ARG, "meta[%d] = %d outside [0, %d)", i, meta[i], D);
+            seg[meta[i] + 1]++;
+        }
+        for (int d = 0; d < D; d++) seg[d + 1] += seg[d];
+        std::vector<int> pos(seg.begin(), seg.end() - 1);
+        for (int i = 0; i < n; i++) perm[pos[meta[i]]++] = i;
+    } else {
+        seg[1] = n;
+        for (int i = 0; i < n; i++) perm[i] = i;
+    }
+    bool ident = true;
+    for (int i = 0; i < n; i++) ident = ident && (perm[i] == i);
+    std::vector<double> ht(ldn, 0.0), hy(ldn, 0.0);
+    std::vector<int> hm(ldn, 0);
+    for (int i = 0; i < n; i++) {
+        ht[i] = (double)t[perm[i]];
+        hy[i] = (double)y[perm[i]];   // zero mean: ref mean/c_meanfunc_zero.cpp:32-50
+        hm[i] = use_meta ? meta[perm[i]] : 0;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->d_pt + (size_t)slot * ldn, ht.data(), sizeof(double) * ldn, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_py + (size_t)slot * ldn, hy.data(), sizeof(double) * ldn, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pmeta + (size_t)slot * ldn, hm.data(), sizeof(int) * ldn, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pseg + (size_t)slot * (D + 1), seg.data(), sizeof(int) * (D + 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pn + slot, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->h_n[slot] = n;
+    c->h_perm[slot] = perm;
+    c->h_perm_identity[slot] = ident ? 1 : 0;
+    return MEDGP_OK;
+}
+
+int medgp_set_prior(medgp_ctx *c, int slot, const uint8_t *flag, const int32_t *type, const uint8_t *is_exp,
+                    const float *p0, const float *p1) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
+    if (slot < -1 || slot >= c->max_slots) return fail(c, MEDGP_ERR_CAPACITY, "slot %d outside [-1, %d)", slot, c->max_slots);
+    if (flag && (!type || !is_exp || !p0 || !p1)) return fail(c, MEDGP_ERR_ARG, "prior arrays must all be given");
+    const int H = c->H;
+    std::vector<MedgpPrior> hp(H);
+    for (int h = 0; h < H; h++) {
+        MedgpPrior p{};
+        if (flag) {
+            if (type[h] < -1 || type[h] > 2) return fail(c, MEDGP_ERR_ARG, "prior type[%d] = %d unsupported (KDE prior type 3 is never constructed by the reference's mains)", h, type[h]);
+            p.p0 = p0[h]; p.p1 = p1[h]; p.type = (int8_t)type[h]; p.flag = flag[h] ? 1 : 0; p.is_exp = is_exp[h] ? 1 : 0;
+        } else { p.type = -1; }
+        hp[h] = p;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint8_t on = flag ? 1 : 0;
+    const int s0 = slot < 0 ? 0 : slot, s1 = slot < 0 ? c->max_slots : slot + 1;
+    for (int s = s0; s < s1; s++) {
+        HIPCHK(c, hipMemcpyAsync(c->d_prior + (size_t)s * H, hp.data(), sizeof(MedgpPrior) * H, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_prior_on + s, &on, 1, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MEDGP_OK;
+}
+
+int medgp_nlml_grad_device(medgp_ctx *c, int nbatch, const int32_t *slots, const double *theta_dev, int flag_grad,
+                           double *nlml_dev, double *grad_dev, int32_t *status_dev) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (!slots || !theta_dev || !nlml_dev) return fail(c, MEDGP_ERR_ARG, "NULL argument");
+    if (flag_grad && !grad_dev) return fail(c, MEDGP_ERR_ARG, "grad is NULL with flag_grad set");
+    if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int max_n = 0, rc;
+    if ((rc = set_batch(c, nbatch, slots, &max_n))) return rc;
+    return run_pipeline(c, nbatch, max_n, theta_dev, flag_grad, false, nlml_dev, grad_dev, status_dev);
+}
+
+int medgp_nlml_grad(medgp_ctx *c, int nbatch, const int32_t *slots, const double *theta, int flag_grad, double *nlml,
+                    double *grad, int32_t *status) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (!slots || !theta || !nlml) return fail(c, MEDGP_ERR_ARG, "NULL argument");
+    if (flag_grad && !grad) return fail(c, MEDGP_ERR_ARG, "grad is NULL with flag_grad set");
+    if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
+    if (nbatch < 1 || nbatch > c->max_batch) return fail(c, MEDGP_ERR_CAPACITY, "nbatch %d outside [1, %d]", nbatch, c->max_batch);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t H = c->H;
+    HIPCHK(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * nbatch * H, hipMemcpyHostToDevice, c->stream));
+    int rc = medgp_nlml_grad_device(c, nbatch, slots, c->d_theta, flag_grad, c->d_nlml, c->d_grad, c->d_status_out);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(nlml, c->d_nlml, sizeof(double) * nbatch, hipMemcpyDeviceToHost, c->stream));
+    if (flag_grad) HIPCHK(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * nbatch * H, hipMemcpyDeviceToHost, c->stream));
+    if (status) HIPCHK(c, hipMemcpyAsync(status, c->d_status_out, sizeof(int32_t) * nbatch, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MEDGP_OK;
+}
+
+int medgp_get_factor(medgp_ctx *c, int b, float *alpha, float *linv, float *beta) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (b < 0 || b >= c->last_nbatch) return fail(c, MEDGP_ERR_ARG, "batch entry %d outside the last call's [0, %d)", b, c->last_nbatch);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int slot = c->h_bslot[b], n = c->h_n[slot], ld = c->ldn;
+    const std::vector<int> &perm = c->h_perm[slot];
+    int st = 0;
+    HIPCHK(c, hipMemcpyAsync(&st, c->d_status + b, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (st < 0) return fail(c, MEDGP_ERR_ARG, "batch entry %d failed (status %d); no factor available", b, st);
+    if (alpha) {
+        std::vector<double> ha(n);
+        HIPCHK(c, hipMemcpy(ha.data(), c->dev.alpha + (size_t)b * ld, sizeof(double) * n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++) alpha[perm[i]] = (float)ha[i];
+    }
+    if (beta) {
+        double sc[4];
+        HIPCHK(c, hipMemcpy(sc, c->dev.scal + (size_t)b * 4, sizeof(sc), hipMemcpyDeviceToHost));
+        *beta = (float)sc[1];
+    }
+    if (linv) {
+        if (!c->h_perm_identity[slot])
+            return fail(c, MEDGP_ERR_ARG, "L^-1 is only exported for patients already grouped by output (the reference loader's order)");
+        std::vector<double> hx((size_t)n * ld);
+        HIPCHK(c, hipMemcpy(hx.data(), c->dev.Linv + (size_t)b * ld * ld, sizeof(double) * n * ld, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) linv[(size_t)i * n + j] = (j <= i) ? (float)hx[(size_t)i * ld + j] : 0.0f;   // ref: c_inference_exact.cpp:139-143
+    }
+    return MEDGP_OK;
+}
+
+int medgp_fit_predict(medgp_ctx *c, int slot, const double *theta, int nstar, const int32_t *meta2, const float *t2,
+                      float *mean, float *var, int32_t *status) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (!theta || !t2 || !mean || !var || nstar < 1) return fail(c, MEDGP_ERR_ARG, "bad argument");
+    if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
+    if (c->kidx == MEDGP_KERNEL_LMC_SM && !meta2) return fail(c, MEDGP_ERR_ARG, "meta2 is NULL for the multi-output kernel");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (nstar > c->pred_cap) {
+        int cap = std::max(nstar, 64), rc;
+        if ((rc = dalloc(c, &c->d_t2, cap))) return rc;
+        if ((rc = dalloc(c, &c->d_meta2, cap))) return rc;
+        if ((rc = dalloc(c, &c->d_mean, cap))) return rc;
+        if ((rc = dalloc(c, &c->d_var, cap))) return rc;
+        if ((rc = dalloc(c, &c->d_ks, (size_t)cap * c->ldn))) return rc;
+        c->pred_cap = cap;
+    }
+    int32_t s1 = slot;
+    int max_n = 0, rc;
+    if ((rc = set_batch(c, 1, &s1, &max_n))) return rc;
+    std::vector<double> ht2(nstar);
+    std::vector<int> hm2(nstar, 0);
+    for (int j = 0; j < nstar; j++) {
+        ht2[j] = (double)t2[j];
+        if (meta2 && c->kidx == MEDGP_KERNEL_LMC_SM) {
+            if (meta2[j] < 0 || meta2[j] >= c->D) return fail(c, MEDGP_ERR_ARG, "meta2[%d] = %d outside [0, %d)", j, meta2[j], c->D);
+            hm2[j] = meta2[j];
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * c->H, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_t2, ht2.data(), sizeof(double) * nstar, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_meta2, hm2.data(), sizeof(int) * nstar, hipMemcpyHostToDevice, c->stream));
+    if ((rc = run_pipeline(c, 1, max_n, c->d_theta, 0, true, nullptr, nullptr, nullptr))) return rc;
+    {
+        Launcher l(c, KID_PREDICT);
+        hipLaunchKernelGGL(k_predict_v0, dim3(nstar), dim3(256), 0, c->stream, c->dev, 0, nstar, c->d_meta2, c->d_t2, c->d_ks, c->d_mean, c->d_var);
+    }
+    HIPCHK(c, hipGetLastError());
+    int st = 0;
+    HIPCHK(c, hipMemcpyAsync(mean, c->d_mean, sizeof(float) * nstar, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(var, c->d_var, sizeof(float) * nstar, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (status) *status = st;
+    return MEDGP_OK;
+}
+
+int medgp_profile_enable(medgp_ctx *c, int enable) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (!enable && c->profiling) { int rc = drain_events(c); if (rc) return rc; }
+    c->profiling = enable != 0;
+    return MEDGP_OK;
+}
+int medgp_profile_num_kernels(void) { return KID_COUNT; }
+const char *medgp_profile_kernel_name(int k) { return (k >= 0 && k < KID_COUNT) ? kKernelNames[k] : ""; }
+int medgp_profile_read(medgp_ctx *c, int k, double *ms_total, int64_t *launches) {
+    if (!c || k < 0 || k >= KID_COUNT) return MEDGP_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = drain_events(c);
+    if (rc) return rc;
+    if (ms_total) *ms_total = c->prof_ms[k];
+    if (launches) *launches = c->prof_n[k];
+    return MEDGP_OK;
+}
+int medgp_profile_reset(medgp_ctx *c) {
+    if (!c) return MEDGP_ERR_ARG;
+    int rc = drain_events(c);
+    if (rc) return rc;
+    for (int k = 0; k < KID_COUNT; k++) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    return MEDGP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// medgp_dev.h -- device-side data layout shared by all kernels of libmedgp_hip.so.
+//
+// HBM layout (one context = one device, one covariance family):
+//   patient slots   : t, y (fp64, widened once from the caller's float), meta (int32), all
+//                     [max_slots][ldn]; observations stably grouped by output, seg[D+1] offsets.
+//   prior descriptor: [max_slots][H] packed {type, flag, exp, p0, p1}.
+//   per batch entry : hyp block (sigma^2, B_q, w_q, c_q), cos/sin tables [Q][ldn],
+//                     two ldn x ldn fp64 matrices (K -> L -> W, and L^-1), vectors z / alpha [ldn],
+//                     block sums S, SM, SV [Q][D][D], scalars, status.
+// ldn = max_n rounded up to 64; matrices are row-major with leading dimension ldn.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MEDGP_TILE 64
+
+struct MedgpPrior {          // one hyper of one slot
+    float p0, p1;
+    int8_t type;             // -1 none, 0 clamp, 1 normal, 2 laplace  (ref: prior/c_prior.h:50-53)
+    uint8_t flag, is_exp, pad;
+};
+
+struct MedgpDev {
+    // family
+    int kidx, Q, D, R, H, nlik;
+    int ldn, max_slots, max_batch;
+    int hyp_stride;          // doubles per batch entry in `hyp`
+    double pi;
+    // patients
+    const int *pn;           // [slot] n
+    const double *pt, *py;   // [slot][ldn]
+    const int *pmeta;        // [slot][ldn]
+    const int *pseg;         // [slot][D+1]
+    const MedgpPrior *prior; // [slot][H]
+    const uint8_t *prior_on; // [slot]
+    // batch
+    const int *bslot;        // [nbatch]
+    double *hyp;             // [batch][hyp_stride]: sig2[D] | B[Q*D*D] | w[Q] | c[Q]
+    double *cs, *sn;         // [batch][Q][ldn]
+    double *Kmat, *Linv;     // [batch][ldn*ldn]
+    double *z, *alpha;       // [batch][ldn]
+    double *scal;            // [batch][4]: logdet, quad, -, -
+    int *status;             // [batch]
+    double *S, *SM, *SV;     // [batch][Q*D*D]
+};
+
+__host__ __device__ inline int medgp_roundup(int x, int m) { return (x + m - 1) / m * m; }
+// offsets inside the hyp block
+__host__ __device__ inline int hyp_off_sig2(const MedgpDev &) { return 0; }
+__host__ __device__ inline int hyp_off_B(const MedgpDev &d) { return d.D; }
+__host__ __device__ inline int hyp_off_w(const MedgpDev &d) { return d.D + d.Q * d.D * d.D; }
+__host__ __device__ inline int hyp_off_c(const MedgpDev &d) { return d.D + d.Q * d.D * d.D + d.Q; }
