@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- per-patient nlml+gradient evaluations/s of the MI355X-native MedGP hot path.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run,
+one rank per GPU).  Prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json metric "per-patient log-lik+grad evals/sec at D=24 N=512"): the per-GPU shard of
+config 4 -- 512 synthetic patients x N=512 observations, D=24 outputs, Q=5, R=8 (H=1114 hypers), LMC-SM kernel,
+Gaussian-MO likelihood, zero mean, hierarchical-gamma prior (mode 2), fp64.  One step = one nlml+gradient
+evaluation of every patient of the shard (one theta each).  Weak scaling: every rank owns 512 patients; the
+cohort is sharded with no data-path collective (patients are independent).  Inputs (patients, theta) are
+resident in HBM before the timed region; outputs stay in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X dense fp64 (vector = matrix) peak, AMD spec; see DESIGN.md section 5
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def alg_work(kernel, N, Q, D, H):
+    """Algorithmic work of ONE patient in one launch of `kernel`.
+    Returns (flop, bytes, bound)."""
+    pairs = Q * N * (N + 1) / 2
+    table = {
+        "k_prep": (Q * D * D * 2 * 8 + 40.0 * Q * N, 8.0 * (H + 2 * Q * N), "hbm"),
+        "k_assemble": (40.0 * pairs, 8.0 * N * N / 2, "mfma"),
+        "k_potrf": (N ** 3 / 3.0 + 2.0 * N * N, 8.0 * N * N, "mfma"),
+        "k_trtri": (N ** 3 / 3.0 + 2.0 * N * N, 8.0 * N * N, "mfma"),
+        "k_lauum": (N ** 3 / 3.0 + 2.0 * N * N, 8.0 * N * N, "mfma"),
+        "k_gradbins": (40.0 * pairs, 8.0 * N * N / 2, "mfma"),
+        "k_lauum_grad": (N ** 3 / 3.0 + 2.0 * N * N + 40.0 * pairs, 8.0 * N * N / 2, "mfma"),
+        "k_epilogue": (2.0 * Q * D * D * 8 + 8.0 * H, 8.0 * (2 * H + 3 * Q * D * D), "hbm"),
+    }
+    return table.get(kernel, (0.0, 0.0, "hbm"))
+
+
+def aggregate_time(t_local, world):
+    """max over ranks of the local wall time (the driver's contract)."""
+    if world <= 1:
+        return float(t_local)
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl":
+        tt = torch.tensor([t_local], dtype=torch.float64, device="cuda")
+    else:
+        tt = torch.tensor([t_local], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def result_line(value, n_gpus, steps, warmup, ms_per_step, workload, extra):
+    line = {
+        "metric": "per-patient nlml+grad evals/sec at D=24 N=512",
+        "value": value,
+        "unit": "evals/s",
+        "n_gpus": n_gpus,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,   # BASELINE.md holds no published number for this metric
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": workload},
+    }
+    line.update(extra)
+    return line
+
+
+def cpu_baseline(D, N, Q, R, seed, budget_s=12.0):
+    """The oracle ("port" of the reference's algorithm, per-hyper gradient loop as
+    c_kernel_LMC_SM.cpp:222-325) timed on this box's host cores on a bounded sample of the same workload."""
+    from medgp_amd import synth
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    pr = O.Prior.hier_gamma(Q, D, R, 0.01, 0.01)
+    n_eval, t0 = 0, time.perf_counter()
+    while True:
+        m, t, y = synth.patient(seed, n_eval, D, N)
+        th = synth.theta(seed, n_eval, 7, Q, D, R)
+        r = O.nlml_grad(7, Q, D, R, m, t, y, th, flag_grad=True, grad_mode=O.GRAD_PER_HYPER, nthreads=cores, prior=pr)
+        assert r["ok"]
+        n_eval += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s and n_eval >= 2:
+            break
+        if n_eval >= 64:
+            break
+    return {"value": n_eval / el, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"{n_eval} patients of the same synthetic cohort (D={D}, N={N}, Q={Q}, R={R}), nlml+grad, "
+                      f"oracle per-hyper gradient loop, OpenMP over hypers, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--patients", type=int, default=512, help="patients per GPU")
+    ap.add_argument("--n", type=int, default=512)
+    ap.add_argument("--D", type=int, default=24)
+    ap.add_argument("--Q", type=int, default=5)
+    ap.add_argument("--R", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prior", action="store_true")
+    ap.add_argument("--flag-grad", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import medgp_amd
+    from medgp_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+
+    D, N, Q, R, P = args.D, args.n, args.Q, args.R, args.patients
+    H = synth.num_hyp(7, Q, D, R)
+    first = rank * P   # weak scaling: rank r owns global patients [r*P, (r+1)*P)
+    ctx = medgp_amd.Context(7, Q, D, R, device=local_rank)
+    ctx.reserve(P, N, P)
+    thetas = np.empty((P, H))
+    for s in range(P):
+        m, t, y = synth.patient(args.seed, first + s, D, N)
+        ctx.set_patient(s, m, t, y)
+        thetas[s] = synth.theta(args.seed, first + s, 7, Q, D, R)
+    if not args.no_prior:
+        ctx.set_prior(-1, *synth.hier_gamma_prior(Q, D, R, 0.01))
+    slots = np.arange(P, dtype=np.int32)
+    theta_d = torch.from_numpy(thetas).to(dev)
+    nlml_d = torch.empty(P, dtype=torch.float64, device=dev)
+    grad_d = torch.empty((P, H), dtype=torch.float64, device=dev)
+    stat_d = torch.empty(P, dtype=torch.int32, device=dev)
+
+    def step():
+        ctx.nlml_grad_device(slots, theta_d.data_ptr(), args.flag_grad, nlml_d.data_ptr(), grad_d.data_ptr(), stat_d.data_ptr())
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    # HIP events around every kernel launch on the launch stream, live over the timed region
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    t_local = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    t = aggregate_time(t_local, world)
+
+    st = stat_d.cpu().numpy()
+    nl = nlml_d.cpu().numpy()
+    assert np.all(st >= 0) and np.all(np.isfinite(nl)), "evaluation failed inside the timed region"
+
+    if rank == 0:
+        value = world * P * args.steps / t
+        # dominant kernel + roofline from the live HIP-event timings
+        tot = {k: v[0] for k, v in prof.items() if v[1] > 0}
+        dom = max(tot, key=tot.get)
+        avg_ms = prof[dom][0] / prof[dom][1]
+        flop, byts, bound = alg_work(dom, N, Q, D, H)
+        if bound == "mfma":
+            achieved = flop * P / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / FP64_PEAK_TFLOPS}
+        else:
+            achieved = byts * P / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+        roof.update({"traffic": None, "kernel": dom, "avg_launch_ms": avg_ms,
+                     "alg_per_patient": {"flop": flop, "bytes": byts},
+                     "kernel_ms_per_step": {k: round(v[0] / max(args.steps, 1), 4) for k, v in prof.items() if v[1] > 0}})
+        f_alg = N ** 3 + 6 * N * N + 80 * Q * N * (N + 1) / 2
+        extra = {
+            "roofline": roof,
+            "end_to_end": {"flop_per_eval": f_alg, "tflops": f_alg * value / world / 1e12,
+                           "frac_fp64_peak": f_alg * value / world / 1e12 / FP64_PEAK_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            extra["cpu_baseline"] = cpu_baseline(D, N, Q, R, args.seed)
+        line = result_line(value, world, args.steps, args.warmup, 1e3 * t / args.steps,
+                           f"config 4 shard: {P} patients/GPU x N={N}, D={D}, Q={Q}, R={R}, H={H}, LMC-SM + hier-gamma prior, nlml+grad",
+                           extra)
+        line["config"].update({"patients_per_gpu": P, "N": N, "D": D, "Q": Q, "R": R, "H": H,
+                               "parallelism": f"patient-sharded x{world} (no collective)"})
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

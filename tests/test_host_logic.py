@@ -1,0 +1,53 @@
+"""Host-side logic: synthetic cohort generator, sharding, bench aggregation; world_size-2 gloo run."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from medgp_amd import shard, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_synth_shapes_and_determinism():
+    m, t, y = synth.patient(1, 3, 24, 512)
+    m2, t2, y2 = synth.patient(1, 3, 24, 512)
+    assert m.dtype == np.int32 and t.dtype == np.float32 and y.dtype == np.float32
+    np.testing.assert_array_equal(t, t2)
+    np.testing.assert_array_equal(y, y2)
+    assert np.all(np.diff(m) >= 0) and np.bincount(m, minlength=24).tolist() == [22] * 8 + [21] * 16
+    for d in range(24):
+        assert np.all(np.diff(t[m == d]) >= 0)
+    assert len(np.unique(t)) < t.size           # shared draw times exist
+    th = synth.theta(1, 3, 7, 5, 24, 8)
+    assert th.shape == (1114,) and synth.num_hyp(7, 5, 24, 8) == 1114
+    assert synth.num_hyp(7, 5, 2, 2) == 42 and synth.num_hyp(7, 5, 64, 8) == 2954
+    mi, ti, yi = synth.patient(1, 3, 24, 512, interleave=True)
+    assert not np.all(np.diff(mi) >= 0) and sorted(ti.tolist()) == sorted(t.tolist())
+
+
+def test_lpt_partition_balanced_and_complete():
+    rng = np.random.default_rng(0)
+    ns = rng.integers(20, 900, size=203)
+    parts = shard.lpt_partition(ns, 8)
+    allidx = np.sort(np.concatenate(parts))
+    np.testing.assert_array_equal(allidx, np.arange(203))
+    loads = np.array([shard.cost(ns[p]).sum() for p in parts])
+    assert loads.max() / loads.mean() < 1.05
+    again = shard.lpt_partition(ns, 8)
+    for a, b in zip(parts, again):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(shard.weak_shard(512, 3), np.arange(1536, 2048))
+
+
+def test_two_rank_gloo_sharded_evaluation_matches_single_process():
+    """N>1 path on CPU: two gloo ranks evaluate disjoint shards (through the oracle, the only CPU evaluator
+    there is -- test infrastructure), rank 0 gathers; results must be bit-identical to one process."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541",
+                          os.path.join(ROOT, "tests", "gloo_shard_worker.py")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "GLOO_SHARD_OK" in out.stdout

@@ -1,0 +1,163 @@
+"""CPU tests of the oracle: pinned against the committed golden vectors (reference-recorded nlml values,
+the reference's own fastkernel.py outputs), cross-checked by finite differences and by an independent
+numpy/scipy evaluation.  No GPU needed."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+from oracle import oracle as O
+from medgp_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _np_nlml(kidx, Q, D, R, meta, t, y, theta, pi=O.REF_PI):
+    """Independent fp64 numpy/scipy statement of the LMC-SM nlml."""
+    t = t.astype(np.float64)
+    y = y.astype(np.float64)
+    sig = np.exp(theta[:D])
+    A = theta[D:D + Q * D * R].reshape(Q, D, R)
+    mu = np.exp(theta[D + Q * D * R: D + Q * D * R + Q])
+    v = np.exp(theta[D + Q * D * R + Q: D + Q * D * R + 2 * Q])
+    kap = np.exp(theta[D + Q * (D * R + 2):]).reshape(Q, D)
+    r = np.abs(t[:, None] - t[None, :])
+    K = np.zeros((t.size, t.size))
+    for q in range(Q):
+        B = A[q] @ A[q].T + np.diag(kap[q])
+        K += B[np.ix_(meta, meta)] * np.cos(2 * pi * r * mu[q]) * np.exp(-2 * (pi * v[q]) ** 2 * r * r)
+    K[np.diag_indices_from(K)] += sig[meta] ** 2
+    L = sla.cholesky(K, lower=True)
+    alpha = sla.cho_solve((L, True), y)
+    return 0.5 * y @ alpha + np.log(np.diag(L)).sum() + 0.5 * t.size * np.log(2 * pi)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "appendixA_*.npz"))))
+def test_oracle_vs_recorded_reference(path):
+    """SURVEY section 8c contract 2: fp64 restatement vs the compiled fp32 reference, nlml rel <= 1e-6."""
+    g = np.load(path)
+    D, N, Q, R = int(g["D"]), int(g["N"]), int(g["Q"]), int(g["R"])
+    want_grad = N <= 256
+    r = O.nlml_grad(7, Q, D, R, g["meta"], g["t"], g["y"], g["theta"], flag_grad=want_grad, nthreads=4)
+    assert r["ok"] and r["status"] == 0
+    assert abs(r["nlml"] - float(g["ref_fp32_nlml"])) <= 1e-6 * abs(float(g["ref_fp32_nlml"]))
+    assert abs(r["nlml"] - float(g["oracle_nlml"])) <= 1e-12 * abs(r["nlml"])
+    if want_grad:
+        np.testing.assert_allclose(r["grad"], g["oracle_grad"], rtol=1e-9, atol=1e-9 * np.abs(g["oracle_grad"]).max())
+
+
+def test_oracle_prior_mode2_vs_recorded_reference():
+    g = np.load(os.path.join(GOLD, "appendixA_D24_N512.npz"))
+    D, N, Q, R = int(g["D"]), int(g["N"]), int(g["Q"]), int(g["R"])
+    pr = O.Prior.hier_gamma(Q, D, R, 0.01, 0.01)
+    r = O.nlml_grad(7, Q, D, R, g["meta"], g["t"], g["y"], g["theta"], flag_grad=False, prior=pr)
+    ref = float(g["ref_fp32_nlml_prior2"])
+    assert abs(r["nlml"] - ref) <= 1e-6 * ref
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "fastkernel_*.npz"))))
+def test_oracle_vs_fastkernel(path):
+    """B_q and k_q against the reference's own Python (fastkernel.py:13-48), which uses numpy's pi."""
+    g = np.load(path)
+    Q, D, R, hyp = int(g["Q"]), int(g["D"]), int(g["R"]), g["hyp"]
+    B = O.coregional(Q, D, R, hyp[D:])
+    np.testing.assert_allclose(B, g["B"], rtol=1e-13, atol=1e-14)
+    for q in range(Q):
+        k = np.array([O.sm_k(x * x, g["mu"][q], g["v"][q], pi=np.pi) for x in g["x"]])
+        np.testing.assert_allclose(k, g["resp"][q], rtol=0, atol=2e-13)   # fastkernel forms r^2 by expansion
+    # with the reference C++'s truncated literal the kernel moves by O(1e-8) only
+    k_ref = np.array([O.sm_k(x * x, g["mu"][0], g["v"][0]) for x in g["x"]])
+    assert np.abs(k_ref - g["resp"][0]).max() < 1e-6
+
+
+@pytest.mark.parametrize("D,N,Q,R", [(2, 40, 3, 2), (5, 63, 2, 3)])
+def test_oracle_vs_numpy_and_fd(D, N, Q, R):
+    m, t, y = synth.patient(3, 0, D, N, interleave=True)
+    th = synth.theta(3, 0, 7, Q, D, R)
+    r = O.nlml_grad(7, Q, D, R, m, t, y, th, grad_mode=O.GRAD_PER_HYPER)
+    assert abs(r["nlml"] - _np_nlml(7, Q, D, R, m, t, y, th)) <= 1e-11 * abs(r["nlml"])
+    rb = O.nlml_grad(7, Q, D, R, m, t, y, th, grad_mode=O.GRAD_BLOCKED)
+    np.testing.assert_allclose(rb["grad"], r["grad"], rtol=1e-10, atol=1e-10 * np.abs(r["grad"]).max())
+    # SURVEY contract 3: central finite differences of the oracle's own nlml
+    eps = 1e-6
+    gs = np.abs(r["grad"]).max()
+    for h in range(th.size):
+        tp, tm = th.copy(), th.copy()
+        tp[h] += eps
+        tm[h] -= eps
+        fd = (O.nlml_grad(7, Q, D, R, m, t, y, tp, flag_grad=False)["nlml"]
+              - O.nlml_grad(7, Q, D, R, m, t, y, tm, flag_grad=False)["nlml"]) / (2 * eps)
+        assert abs(fd - r["grad"][h]) <= 2e-6 * max(abs(r["grad"][h]), 1e-2 * gs), (h, fd, r["grad"][h])
+
+
+@pytest.mark.parametrize("kidx,Q", [(8, 3), (0, 1)])
+def test_oracle_single_output_kernels_fd(kidx, Q):
+    m, t, y = synth.patient(5, 1, 1, 50)
+    th = synth.theta(5, 1, kidx, Q, 1, 0)
+    r = O.nlml_grad(kidx, Q, 1, 0, None, t, y, th)
+    assert r["ok"]
+    eps = 1e-6
+    for h in range(th.size):
+        tp, tm = th.copy(), th.copy()
+        tp[h] += eps
+        tm[h] -= eps
+        fd = (O.nlml_grad(kidx, Q, 1, 0, None, t, y, tp, flag_grad=False)["nlml"]
+              - O.nlml_grad(kidx, Q, 1, 0, None, t, y, tm, flag_grad=False)["nlml"]) / (2 * eps)
+        assert abs(fd - r["grad"][h]) <= 2e-6 * max(abs(r["grad"][h]), 1e-2 * np.abs(r["grad"]).max())
+
+
+def test_oracle_prior_terms():
+    D, N, Q, R = 3, 30, 2, 2
+    m, t, y = synth.patient(9, 0, D, N)
+    th = synth.theta(9, 0, 7, Q, D, R)
+    base = O.nlml_grad(7, Q, D, R, m, t, y, th)
+    pr = O.Prior.hier_gamma(Q, D, R, 0.01, 0.01)
+    pr.type[D] = 0   # clamp the first A entry (ref: c_prior.cpp:133-138)
+    r = O.nlml_grad(7, Q, D, R, m, t, y, th, prior=pr)
+    A = th[D:D + Q * D * R]
+    kap = np.exp(th[D + Q * (D * R + 2):])
+    b = np.float64(np.float32(0.01))
+    lp = np.sum(-A[1:] ** 2 / 2 - np.log(2 * O.REF_PI) / 2) + np.sum(-kap / b - np.log(2 * b))
+    assert abs((base["nlml"] - lp) - r["nlml"]) < 1e-9 * abs(r["nlml"])
+    assert r["grad"][D] == 0.0
+    np.testing.assert_allclose(r["grad"][D + 1:D + Q * D * R], base["grad"][D + 1:D + Q * D * R] + A[1:], rtol=1e-12)
+    k0 = D + Q * (D * R + 2)
+    np.testing.assert_allclose(r["grad"][k0:], base["grad"][k0:] + kap / b, rtol=1e-12)
+    np.testing.assert_array_equal(r["grad"][:D], base["grad"][:D])
+
+
+def test_oracle_failure_semantics():
+    D, Q, R = 2, 2, 2
+    th = synth.theta(1, 0, 7, Q, D, R)
+    # n <= 2 -> false (ref: c_objective_one.cpp:51)
+    r = O.nlml_grad(7, Q, D, R, np.array([0, 1], np.int32), np.array([1, 2], np.float32), np.array([0, 1], np.float32), th)
+    assert not r["ok"] and r["status"] == -1
+    # exact duplicates + vanishing noise: K is singular, ten jitters of 1e-70 cannot rescue it
+    th2 = th.copy()
+    th2[:D] = -80.0
+    m = np.zeros(6, np.int32)
+    t = np.array([1, 1, 1, 2, 2, 2], np.float32)
+    r = O.nlml_grad(7, Q, D, R, m, t, np.ones(6, np.float32), th2)
+    assert not r["ok"] and r["status"] == -1
+
+
+def test_oracle_predict_vs_numpy():
+    D, N, Q, R = 2, 35, 3, 2
+    m, t, y = synth.patient(4, 0, D, N)
+    th = synth.theta(4, 0, 7, Q, D, R)
+    m2 = np.array([0, 1, 1], np.int32)
+    t2 = np.array([10.5, 77.0, 150.25], np.float32)
+    r = O.fit_predict(7, Q, D, R, m, t, y, th, m2, t2)
+    K = O.gram(7, Q, D, R, m, t, th)
+    # cross covariances through the oracle's own Gram on the stacked set, noise removed
+    ma, ta = np.concatenate([m, m2]), np.concatenate([t, t2])
+    Ka = O.gram(7, Q, D, R, ma, ta, th)
+    sig2 = np.exp(th[:D]) ** 2
+    ks = Ka[:N, N:]
+    kss = np.diag(Ka[N:, N:]) - sig2[m2]
+    mean = ks.T @ np.linalg.solve(K, y.astype(np.float64))
+    var = kss - np.einsum("ij,ij->j", ks, np.linalg.solve(K, ks)) + sig2[m2]
+    np.testing.assert_allclose(r["mean"], mean, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(r["var"], var, rtol=1e-9, atol=1e-11)

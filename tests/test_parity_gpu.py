@@ -1,0 +1,252 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, the committed golden
+fixtures, and size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (SURVEY section 8c contract 1, north_star "<= 1e-6 rel on log-lik and gradients"):
+  nlml  : |d| <= 1e-10 * |ref|
+  grad_h: |d| <= 1e-6 * max(|ref_h|, 1e-3 * max|ref|)      (observed ~1e-11)
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import medgp_amd
+from medgp_amd import synth
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+NLML_RTOL = 1e-10
+GRAD_RTOL = 1e-6
+
+
+def assert_parity(nlml, grad, ref, tag=""):
+    assert abs(nlml - ref["nlml"]) <= NLML_RTOL * abs(ref["nlml"]), (tag, nlml, ref["nlml"])
+    if grad is not None:
+        gs = np.abs(ref["grad"]).max()
+        err = np.abs(grad - ref["grad"]) / np.maximum(np.abs(ref["grad"]), 1e-3 * gs)
+        assert err.max() <= GRAD_RTOL, (tag, int(err.argmax()), err.max())
+
+
+def make_ctx(kidx, Q, D, R, pts, max_batch=None):
+    ctx = medgp_amd.Context(kidx, Q, D, R)
+    nmax = max(p[1].shape[0] for p in pts)
+    ctx.reserve(len(pts), max(nmax, 1), max_batch or len(pts))
+    for s, (m, t, y) in enumerate(pts):
+        ctx.set_patient(s, m if kidx == 7 else None, t, y)
+    return ctx
+
+
+@pytest.mark.parametrize("D,N,Q,R,P,interleave", [
+    (2, 150, 5, 2, 3, False),     # BASELINE config 1 shape
+    (2, 256, 5, 2, 8, False),     # config 2 shape (reduced P)
+    (2, 97, 5, 2, 3, True),       # ragged n, caller order not grouped by output
+    (24, 512, 5, 8, 2, False),    # config 4 shape (reduced P)
+    (7, 65, 3, 4, 4, True),
+    (3, 3, 2, 2, 2, False),       # smallest n the reference accepts
+])
+def test_lmc_parity_vs_oracle(D, N, Q, R, P, interleave):
+    pts, th = synth.cohort(101, P, D, N, Q=Q, R=R, interleave=interleave)
+    ctx = make_ctx(7, Q, D, R, pts)
+    nlml, grad, st = ctx.nlml_grad(np.arange(P), th, True)
+    nlml0, _, st0 = ctx.nlml_grad(np.arange(P), th, False)
+    for p, (m, t, y) in enumerate(pts):
+        ref = O.nlml_grad(7, Q, D, R, m, t, y, th[p], nthreads=4)
+        assert st[p] == ref["status"] == 0 and st0[p] == 0
+        assert_parity(nlml[p], grad[p], ref, f"p{p}")
+        assert nlml0[p] == nlml[p]    # nlml-only path: same bits
+    ctx.close()
+
+
+def test_ragged_batch_and_prior():
+    D, Q, R = 4, 3, 2
+    ns = [5, 64, 65, 130, 17, 200]
+    pts = [synth.patient(55, p, D, n) for p, n in enumerate(ns)]
+    th = np.stack([synth.theta(55, p, 7, Q, D, R, sparse_frac=0.5) for p in range(len(ns))])
+    ctx = make_ctx(7, Q, D, R, pts)
+    f, ty, ex, p0, p1 = synth.hier_gamma_prior(Q, D, R, 0.01)
+    # test-time clamp of the exactly-zero A entries of patient 2 (ref: c_prior.cpp:118-140)
+    ty2, f2 = ty.copy(), f.copy()
+    z = np.where(th[2][D:D + Q * D * R] == 0.0)[0] + D
+    ty2[z] = 0
+    ctx.set_prior(-1, f, ty, ex, p0, p1)
+    ctx.set_prior(2, f2, ty2, ex, p0, p1)
+    ctx.set_prior(4)   # no prior on patient 4
+    nlml, grad, st = ctx.nlml_grad(np.arange(len(ns)), th, True)
+    for p, (m, t, y) in enumerate(pts):
+        pr = O.Prior.hier_gamma(Q, D, R, 0.01, 0.01)
+        if p == 2:
+            pr.type[z] = 0
+        if p == 4:
+            pr = None
+        ref = O.nlml_grad(7, Q, D, R, m, t, y, th[p], prior=pr)
+        assert_parity(nlml[p], grad[p], ref, f"p{p}")
+        if p == 2:
+            assert np.all(grad[p][z] == 0.0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("kidx,Q", [(8, 4), (0, 1)])
+def test_single_output_kernels(kidx, Q):
+    pts = [synth.patient(77, p, 1, 120 + 7 * p) for p in range(3)]
+    th = np.stack([synth.theta(77, p, kidx, Q, 1, 0) for p in range(3)])
+    ctx = make_ctx(kidx, Q, 1, 0, pts)
+    nlml, grad, st = ctx.nlml_grad(np.arange(3), th, True)
+    for p, (m, t, y) in enumerate(pts):
+        ref = O.nlml_grad(kidx, Q, 1, 0, None, t, y, th[p])
+        assert st[p] == 0
+        assert_parity(nlml[p], grad[p], ref)
+    ctx.close()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "appendixA_*.npz"))))
+def test_golden_fixtures(path):
+    """Committed vectors: inputs of the survey's reference run; expected = oracle fp64 (tight) and the
+    compiled reference's recorded fp32 nlml (its own noise floor, 1e-6)."""
+    g = np.load(path)
+    D, N, Q, R = int(g["D"]), int(g["N"]), int(g["Q"]), int(g["R"])
+    ctx = make_ctx(7, Q, D, R, [(g["meta"], g["t"], g["y"])])
+    nlml, grad, st = ctx.nlml_grad([0], g["theta"][None, :], True)
+    assert st[0] == 0
+    assert abs(nlml[0] - float(g["oracle_nlml"])) <= NLML_RTOL * abs(nlml[0])
+    assert abs(nlml[0] - float(g["ref_fp32_nlml"])) <= 1e-6 * abs(nlml[0])
+    if "oracle_grad" in g:
+        assert_parity(nlml[0], grad[0], {"nlml": float(g["oracle_nlml"]), "grad": g["oracle_grad"]})
+    if "oracle_nlml_prior2" in g:
+        ctx.set_prior(0, *synth.hier_gamma_prior(Q, D, R, 0.01))
+        n2, g2, _ = ctx.nlml_grad([0], g["theta"][None, :], True)
+        assert_parity(n2[0], g2[0], {"nlml": float(g["oracle_nlml_prior2"]), "grad": g["oracle_grad_prior2"]})
+        assert abs(n2[0] - float(g["ref_fp32_nlml_prior2"])) <= 1e-6 * abs(n2[0])
+    ctx.close()
+
+
+def test_failure_semantics():
+    D, Q, R = 2, 2, 2
+    th = synth.theta(1, 0, 7, Q, D, R)
+    tiny = (np.array([0, 1], np.int32), np.array([1, 2], np.float32), np.array([0, 1], np.float32))
+    sing = (np.zeros(6, np.int32), np.array([1, 1, 1, 2, 2, 2], np.float32), np.ones(6, np.float32))
+    good = synth.patient(1, 0, D, 40)
+    ctx = make_ctx(7, Q, D, R, [tiny, sing, good])
+    th2 = th.copy()
+    th2[:D] = -80.0
+    nlml, grad, st = ctx.nlml_grad([0, 1, 2], np.stack([th, th2, th]), True)
+    assert st[0] == -1 and np.isnan(nlml[0]) and np.all(np.isnan(grad[0]))     # n <= 2 (c_objective_one.cpp:51)
+    assert st[1] == -1 and np.isnan(nlml[1])                                     # 10 jitters exhausted
+    ref = O.nlml_grad(7, Q, D, R, *good, th)
+    assert st[2] == 0
+    assert_parity(nlml[2], grad[2], ref)
+    # argument errors come back as codes + message, never exit()
+    with pytest.raises(medgp_amd.MedgpError):
+        ctx.nlml_grad([7], th[None, :], True)
+    with pytest.raises(medgp_amd.MedgpError):
+        ctx.set_patient(0, np.array([0, 5, 1], np.int32), np.zeros(3, np.float32), np.zeros(3, np.float32))
+    ctx.close()
+
+
+def test_jitter_retry_matches_oracle():
+    """Borderline matrix: duplicates + noise near fp64 epsilon. The retry count must agree with the
+    oracle whenever both succeed (ref: c_inference_exact.cpp:99-108)."""
+    D, Q, R = 1, 2, 1
+    m = np.zeros(40, np.int32)
+    t = np.repeat(np.linspace(0, 50, 10, dtype=np.float32), 4)
+    y = np.sin(t).astype(np.float32)
+    pts = [(m, t, y)]
+    ctx = make_ctx(7, Q, D, R, pts)
+    th = synth.theta(2, 0, 7, Q, D, R)
+    seen = set()
+    for ls in (-17.0, -18.0, -18.5, -19.0, -30.0):
+        th2 = th.copy()
+        th2[0] = ls
+        nlml, grad, st = ctx.nlml_grad([0], th2[None, :], True)
+        ref = O.nlml_grad(7, Q, D, R, m, t, y, th2)
+        seen.add(int(st[0]))
+        assert -1 <= st[0] <= 10
+        if st[0] == ref["status"] and st[0] >= 0:
+            assert abs(nlml[0] - ref["nlml"]) <= 1e-6 * abs(ref["nlml"])   # ill-conditioned by construction
+    assert -1 in seen
+    ctx.close()
+
+
+def test_get_factor_and_predict():
+    D, N, Q, R = 3, 90, 3, 2
+    m, t, y = synth.patient(8, 0, D, N)
+    th = synth.theta(8, 0, 7, Q, D, R)
+    ctx = make_ctx(7, Q, D, R, [(m, t, y)])
+    ctx.nlml_grad([0], th[None, :], True)
+    alpha, linv, beta = ctx.get_factor(0, N)
+    ref = O.nlml_grad(7, Q, D, R, m, t, y, th, want_alpha=True, want_linv=True)
+    np.testing.assert_allclose(alpha, ref["alpha"], rtol=2e-6, atol=1e-6 * np.abs(ref["alpha"]).max())
+    np.testing.assert_allclose(linv, ref["linv"], rtol=2e-6, atol=1e-6 * np.abs(ref["linv"]).max())
+    assert abs(beta - ref["beta"]) <= 1e-6 * abs(ref["beta"])
+    assert np.all(np.triu(linv, 1) == 0)
+    m2 = np.array([0, 2, 1, 1], np.int32)
+    t2 = np.array([3.5, 77.0, 150.25, float(t[5])], np.float32)
+    mean, var, st = ctx.fit_predict(0, th, m2, t2)
+    rp = O.fit_predict(7, Q, D, R, m, t, y, th, m2, t2)
+    assert st == 0
+    np.testing.assert_allclose(mean, rp["mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(var, rp["var"], rtol=1e-5, atol=1e-6)
+    ctx.close()
+
+
+def test_full_size_properties():
+    """BASELINE sizes (D=24, N=512): properties that need no oracle run.
+    (a) batch-composition invariance: a patient evaluated alone == inside a batch, bit for bit;
+    (b) duplicate patients in different slots give identical bits; run-to-run reproducible;
+    (c) observation-permutation invariance (<= 1e-10);
+    (d) gradient vs central finite differences of the GPU's own nlml on a few hypers."""
+    D, N, Q, R, P = 24, 512, 5, 8, 24
+    pts, th = synth.cohort(31, P, D, N, Q=Q, R=R)
+    pts[5] = pts[3]
+    th[5] = th[3]
+    ctx = make_ctx(7, Q, D, R, pts)
+    nlml, grad, st = ctx.nlml_grad(np.arange(P), th, True)
+    assert np.all(st == 0)
+    n1, g1, _ = ctx.nlml_grad([3], th[3:4], True)
+    assert n1[0] == nlml[3] and np.array_equal(g1[0], grad[3])
+    assert nlml[5] == nlml[3] and np.array_equal(grad[5], grad[3])
+    nlml_b, grad_b, _ = ctx.nlml_grad(np.arange(P), th, True)
+    assert np.array_equal(nlml_b, nlml) and np.array_equal(grad_b, grad)
+    # (c)
+    m, t, y = pts[0]
+    perm = np.random.default_rng(0).permutation(N)
+    ctx.set_patient(1, m[perm], t[perm], y[perm])
+    n2, g2, _ = ctx.nlml_grad([1], th[0:1], True)
+    assert abs(n2[0] - nlml[0]) <= 1e-10 * abs(nlml[0])
+    np.testing.assert_allclose(g2[0], grad[0], rtol=1e-7, atol=1e-9 * np.abs(grad[0]).max())
+    # (d)
+    H = th.shape[1]
+    hs = [0, D - 1, D + 5, D + Q * D * R - 1, D + Q * D * R, D + Q * D * R + Q + 1, H - 1]
+    eps = 1e-6
+    tp = np.repeat(th[0:1], 2 * len(hs), axis=0)
+    for k, h in enumerate(hs):
+        tp[2 * k, h] += eps
+        tp[2 * k + 1, h] -= eps
+    nf, _, _ = ctx.nlml_grad(np.zeros(2 * len(hs), np.int32), tp, False)
+    gs = np.abs(grad[0]).max()
+    for k, h in enumerate(hs):
+        fd = (nf[2 * k] - nf[2 * k + 1]) / (2 * eps)
+        assert abs(fd - grad[0][h]) <= 5e-6 * max(abs(grad[0][h]), 1e-2 * gs), (h, fd, grad[0][h])
+    ctx.close()
+
+
+def test_device_pointer_api_matches_host_api():
+    import torch
+    D, N, Q, R, P = 2, 256, 5, 2, 16
+    pts, th = synth.cohort(5, P, D, N, Q=Q, R=R)
+    ctx = make_ctx(7, Q, D, R, pts)
+    nlml, grad, st = ctx.nlml_grad(np.arange(P), th, True)
+    dev = torch.device("cuda", 0)
+    th_d = torch.from_numpy(th).to(dev)
+    nl_d = torch.empty(P, dtype=torch.float64, device=dev)
+    g_d = torch.empty((P, ctx.H), dtype=torch.float64, device=dev)
+    s_d = torch.empty(P, dtype=torch.int32, device=dev)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.nlml_grad_device(np.arange(P), th_d.data_ptr(), True, nl_d.data_ptr(), g_d.data_ptr(), s_d.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(nl_d.cpu().numpy(), nlml) and np.array_equal(g_d.cpu().numpy(), grad)
+    assert np.array_equal(s_d.cpu().numpy(), st)
+    ctx.set_stream(None)
+    ctx.close()
