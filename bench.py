@@ -78,12 +78,34 @@ def result_line(value, n_gpus, steps, warmup, ms_per_step, workload, extra):
     return line
 
 
-def cpu_baseline(D, N, Q, R, seed, budget_s=12.0):
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(D, N, Q, R, seed, budget_s=10.0):
     """The oracle ("port" of the reference's algorithm, per-hyper gradient loop as
     c_kernel_LMC_SM.cpp:222-325) timed on this box's host cores on a bounded sample of the same workload."""
     from medgp_amd import synth
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     pr = O.Prior.hier_gamma(Q, D, R, 0.01, 0.01)
     n_eval, t0 = 0, time.perf_counter()
     while True:
@@ -93,7 +115,7 @@ def cpu_baseline(D, N, Q, R, seed, budget_s=12.0):
         assert r["ok"]
         n_eval += 1
         el = time.perf_counter() - t0
-        if el >= budget_s and n_eval >= 2:
+        if el >= budget_s:
             break
         if n_eval >= 64:
             break

@@ -25,6 +25,7 @@ def build(force=False):
 
 
 _lib = None
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # no spinning when the box has fewer cores than threads
 
 
 def lib():
