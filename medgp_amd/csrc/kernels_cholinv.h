@@ -1,0 +1,392 @@
+// kernels_cholinv.h -- fused Cholesky + triangular inverse + forward solve for one patient per
+// workgroup, on fp64 MFMA (v_mfma_f64_16x16x4_f64), gfx950.
+//
+// Replaces LAPACKE_spotrf + spotrs + strtri of the reference (ref: inference/c_inference_exact.cpp:96-143).
+//
+// Formulation.  Append the identity below K:  T = [K; I]  (2N x N).  Running the left-looking blocked
+// Cholesky panel recurrence on ALL rows of T,
+//      row_i[C_k] <- ( init_i[C_k] - sum_{j<k} row_i[C_j] L[C_k, C_j]^T ) L_kk^-T ,
+// turns the K rows into L and the identity rows into U = L^-T (the same recurrence that turns an
+// appended y^T into z^T = (L^-1 y)^T).  Every 64-wide step k therefore updates exactly N rows:
+// (nb - k) blocks of K rows with history length 64k and k blocks of U rows with history 64(k - rho):
+// uniform work per step, one 32 x 64 half block per wave (16 waves), all GEMMs on MFMA.
+//
+// Data (row-major, leading dimension ldn):  Kmat: K lower in, L lower out.  Linv: U = L^-T upper out,
+// i.e. (L^-1)[i][j] = U[j][i]; the strictly-lower part of each diagonal 64-block of U is zeroed.
+// MFMA orientation: tiles are computed TRANSPOSED (acc[c][i], c = column inside the block, i = row), so
+// that an accumulator tile is directly the B operand of the triangular solve  out^T = L_kk^-1 acc^T
+// (C/D layout row = (lane>>4) + 4 reg  <->  B operand k = 4 step + (lane>>4)).
+#pragma once
+#include "medgp_dev.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+#define CI_KC 16          // k-columns staged per barrier
+#define CI_THREADS 1024   // 16 waves: 8 blocks x 2 halves per pass
+
+struct CholInvSmem {
+    double Bs[2][64][CI_KC + 2];   // staged chunk of L[C_k rows][kc .. kc+16)
+    double Dk[64][66];             // diagonal block: in D, out L_kk (lower)
+    double Xk[64][66];             // L_kk^-1 (lower)
+    double zacc[64];               // L[C_k, 0:64k] z[0:64k]
+    double rhs[64];
+    double rdiag[16];              // 1 / diag of the current 16x16 tile
+    double red[16];
+    double logdet;
+    int fail;
+};
+
+#define CI_S 66   // LDS row stride (doubles) of Dk / Xk
+
+__device__ inline double readlane_d(double v, int srclane) {   // srclane must be wave-uniform
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, srclane);
+    hi = __builtin_amdgcn_readlane(hi, srclane);
+    return __hiloint2double(hi, lo);
+}
+
+// 16x16 tile product on one wave, operands in LDS (row stride CI_S): returns c + op(A) op(B),
+// op(A)[i][k] = TA ? A[k][i] : A[i][k], op(B)[k][j] = TB ? B[j][k] : B[k][j].
+template <bool TA, bool TB>
+__device__ inline v4d tile_mm(const double *Ap, const double *Bp, v4d c, int li, int g) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        double a = TA ? Ap[(4 * s + g) * CI_S + li] : Ap[li * CI_S + 4 * s + g];
+        double b = TB ? Bp[li * CI_S + 4 * s + g] : Bp[(4 * s + g) * CI_S + li];
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    return c;
+}
+__device__ inline v4d tile_ld(const double *Cp, int li, int g) {
+    v4d c;
+#pragma unroll
+    for (int r = 0; r < 4; r++) c[r] = Cp[(4 * r + g) * CI_S + li];
+    return c;
+}
+__device__ inline void tile_st(double *Cp, v4d c, int li, int g) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) Cp[(4 * r + g) * CI_S + li] = c[r];
+}
+
+// Cholesky + inverse of one 16x16 diagonal tile, register resident (lane i holds row i; lanes >= 16 mirror
+// lanes & 15), cross-lane traffic by v_readlane.  T: tile in Dk (in: D lower, out: L lower);
+// X: tile in Xk (out: full 16x16 inverse, zeros above the diagonal).  Returns false on a bad pivot
+// (LAPACK potf2 rule: pivot <= 0 or NaN).  *logsum += sum log(diag) (computed lane-parallel).
+__device__ inline bool diag16(double *T, double *X, double *rdl, int lane, double *logsum) {
+    const int i = lane & 15;
+    {
+        double a[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) a[c] = T[i * CI_S + c];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            double piv = readlane_d(a[j], j);
+            if (!(piv > 0.0)) return false;
+            double sq = sqrt(piv), rinv = 1.0 / sq;
+            if (lane == j) rdl[j] = rinv;
+            a[j] = (i == j) ? sq : a[j] * rinv;
+#pragma unroll
+            for (int c = j + 1; c < 16; c++) a[c] -= a[j] * readlane_d(a[j], c);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int c = 0; c < 16; c++)
+                if (c <= i) T[i * CI_S + c] = a[c];
+        }
+        // log-det contribution: lane j holds l_jj in a[j]; pick it without dynamic register indexing
+        double dj = a[0];
+#pragma unroll
+        for (int c = 1; c < 16; c++) dj = (i == c) ? a[c] : dj;
+        double lg = log(dj), tot = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) tot += readlane_d(lg, c);
+        *logsum += tot;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // inverse: lane = column i of X;  x_r = -(sum_{k<r} l_rk x_k) / l_rr, x_k = 0 for k < i.
+    // L rows are read back from LDS (wave-uniform addresses: broadcast reads, no stores in between).
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int k = 0; k < r; k++) sacc += T[r * CI_S + k] * x[k];
+        double rdr = rdl[r];
+        x[r] = (r == i) ? rdr : ((r > i) ? -sacc * rdr : 0.0);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) X[c * CI_S + i] = x[c];
+    }
+    return true;
+}
+
+// Cholesky of the 64x64 block in sm.Dk (lower, in place) and its inverse into sm.Xk (lower), on ONE wave:
+// 16x16 tiles, diagonal tiles in registers (diag16), everything else as MFMA tile products out of LDS.
+__device__ inline void diag_factor_wave(CholInvSmem &sm, int lane) {
+    const int li = lane & 15, g = lane >> 4;
+    double *D = &sm.Dk[0][0], *X = &sm.Xk[0][0];
+#define TD(s, t) (D + (16 * (s)) * CI_S + 16 * (t))
+#define TX(s, t) (X + (16 * (s)) * CI_S + 16 * (t))
+    double logsum = 0.0;
+    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int t = 0; t < 4; t++) {
+        if (!diag16(TD(t, t), TX(t, t), sm.rdiag, lane, &logsum)) { if (lane == 0) sm.fail = 1; return; }
+        __builtin_amdgcn_wave_barrier();
+        // panel below: L(s,t) = D(s,t) X(t,t)^T
+#pragma unroll 1
+        for (int s2 = t + 1; s2 < 4; s2++) {
+            v4d c = tile_mm<false, true>(TD(s2, t), TX(t, t), zero4, li, g);
+            __builtin_amdgcn_wave_barrier();
+            tile_st(TD(s2, t), c, li, g);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // trailing: D(s,u) -= L(s,t) L(u,t)^T
+#pragma unroll 1
+        for (int s2 = t + 1; s2 < 4; s2++)
+#pragma unroll 1
+            for (int u = t + 1; u <= s2; u++) {
+                v4d p = tile_mm<false, true>(TD(s2, t), TD(u, t), zero4, li, g);
+                v4d c = tile_ld(TD(s2, u), li, g);
+                tile_st(TD(s2, u), c - p, li, g);
+            }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // inverse, block column t: X(s,t) = -X(s,s) sum_{u=t}^{s-1} L(s,u) X(u,t)
+#pragma unroll 1
+    for (int t = 0; t < 4; t++)
+#pragma unroll 1
+        for (int s2 = t + 1; s2 < 4; s2++) {
+            v4d p = zero4;
+            for (int u = t; u < s2; u++) p = tile_mm<false, false>(TD(s2, u), TX(u, t), p, li, g);
+            // stage P through the (still unused) tile X(s,t) to use it as a B operand
+            tile_st(TX(s2, t), p, li, g);
+            __builtin_amdgcn_wave_barrier();
+            v4d xs = tile_mm<false, false>(TX(s2, s2), TX(s2, t), zero4, li, g);
+            __builtin_amdgcn_wave_barrier();
+            tile_st(TX(s2, t), -xs, li, g);
+            __builtin_amdgcn_wave_barrier();
+        }
+    // zero the strictly-upper tiles of X (consumers read whole 16x16 tiles only on/below the diagonal,
+    // but U_kk is exported from X with zeros)
+#pragma unroll 1
+    for (int t = 1; t < 4; t++)
+        for (int s2 = 0; s2 < t; s2++) tile_st(TX(s2, t), zero4, li, g);
+    if (lane == 0) sm.logdet += logsum;
+#undef TD
+#undef TX
+}
+
+// one factorisation attempt; returns false if a pivot failed
+__device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int want_inv, CholInvSmem &sm) {
+    const int ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
+    double *Lb = L.Kmat + (size_t)b * ld * ld;
+    double *Ub = L.Linv + (size_t)b * ld * ld;
+    double *zz = L.z + (size_t)b * ld;
+    const double *y = L.py + (size_t)slot * ld;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, g = lane >> 4;
+    const int wblk = wave >> 1, whalf = wave & 1;
+
+    if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
+    __syncthreads();
+
+    for (int k = 0; k < nb; k++) {
+        const int c0 = 64 * k;                       // first column of the panel
+        const int nM = nb - k;                       // K-row blocks (first one is the diagonal block)
+        const int ntot = nM + (want_inv ? k : 0);    // + U-row blocks
+        const int npass = (ntot + 7) / 8;
+        const int nch = c0 / CI_KC;                  // history chunks
+        for (int pass = 0; pass < npass; pass++) {
+            const int bidx = pass * 8 + wblk;
+            const bool active = bidx < ntot;
+            const bool isM = bidx < nM;
+            const int rblk = isM ? (k + bidx) : (bidx - nM);           // row block of this wave
+            const int row0 = 64 * rblk + 32 * whalf;                   // first of my 32 rows
+            const double *Hist = isM ? Lb : Ub;
+            const int kstart = isM ? 0 : 64 * rblk;
+            const int cfirst = kstart / CI_KC;
+            v4d acc[4][2];
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+                for (int u = 0; u < 2; u++) acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
+            double zsum = 0.0;
+            // ---- GEMM over the history, B chunk (L[C_k rows]) staged through LDS, double buffered
+            if (nch > 0) {
+                const int srow = tid >> 4, scol = tid & 15;
+                const double *Bsrc = Lb + (size_t)(c0 + srow) * ld + scol;
+                double bnext = Bsrc[0];
+                sm.Bs[0][srow][scol] = bnext;
+                v2d hn[2][2];
+                if (active && cfirst < nch) {
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+                            hn[u][h] = *(const v2d *)(Hist + (size_t)(row0 + 16 * u + li) * ld + cfirst * CI_KC + 8 * h + 2 * g);
+                }
+                __syncthreads();
+                for (int c = 0; c < nch; c++) {
+                    const int buf = c & 1;
+                    if (c + 1 < nch) bnext = Bsrc[(c + 1) * CI_KC];
+                    if (active && c >= cfirst) {
+                        v2d hc[2][2];
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+#pragma unroll
+                            for (int h = 0; h < 2; h++) hc[u][h] = hn[u][h];
+                        if (c + 1 < nch) {
+#pragma unroll
+                            for (int u = 0; u < 2; u++)
+#pragma unroll
+                                for (int h = 0; h < 2; h++)
+                                    hn[u][h] = *(const v2d *)(Hist + (size_t)(row0 + 16 * u + li) * ld + (c + 1) * CI_KC + 8 * h + 2 * g);
+                        }
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+#pragma unroll
+                            for (int ct = 0; ct < 4; ct++) {
+                                const v2d a = *(const v2d *)&sm.Bs[buf][16 * ct + li][8 * h + 2 * g];
+#pragma unroll
+                                for (int s = 0; s < 2; s++)
+#pragma unroll
+                                    for (int u = 0; u < 2; u++)
+                                        acc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], hc[u][h][s], acc[ct][u], 0, 0, 0);
+                            }
+                        }
+                    }
+                    // z history product (pass 0 only): wave 15, lane = panel column
+                    if (pass == 0 && wave == 15) {
+#pragma unroll
+                        for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * zz[c * CI_KC + kk];
+                    }
+                    if (c + 1 < nch) sm.Bs[buf ^ 1][srow][scol] = bnext;
+                    __syncthreads();
+                }
+            }
+            // ---- acc <- init - acc   (init = K block for K rows, 0 for U rows)
+            if (active) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            double init = 0.0;
+                            if (isM) init = Lb[(size_t)(row0 + 16 * u + li) * ld + c0 + 16 * ct + 4 * r + g];
+                            acc[ct][u][r] = init - acc[ct][u][r];
+                        }
+            }
+            if (pass == 0) {
+                // diagonal block (block index 0 = waves 0,1) -> LDS, factor, invert
+                if (wblk == 0) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+                        for (int u = 0; u < 2; u++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) sm.Dk[32 * whalf + 16 * u + li][16 * ct + 4 * r + g] = acc[ct][u][r];
+                }
+                if (wave == 15) sm.zacc[lane] = zsum;
+                __syncthreads();
+                if (wave == 0) {
+                    if (want_inv & 2) {   // DEBUG timing experiment: skip the diagonal factorisation
+                        for (int c = 0; c < 64; c++) { sm.Xk[lane][c] = (lane == c) ? 1.0 : 0.0; }
+                    } else
+                    diag_factor_wave(sm, lane);
+                    if (!sm.fail) {
+                        // z_k = L_kk^-1 (y_k - zacc)
+                        sm.rhs[lane] = ((c0 + lane < n) ? y[c0 + lane] : 0.0) - sm.zacc[lane];
+                        __builtin_amdgcn_wave_barrier();
+                        double s = 0.0;
+                        for (int cc = 0; cc <= lane; cc++) s += sm.Xk[lane][cc] * sm.rhs[cc];
+                        zz[c0 + lane] = s;
+                    }
+                }
+                __syncthreads();
+                if (sm.fail) return false;
+                // store L_kk (lower) and U_kk = L_kk^-T (upper, zeros below)
+                for (int e = tid; e < 64 * 64; e += CI_THREADS) {
+                    int rr = e >> 6, cc = e & 63;
+                    if (cc <= rr) Lb[(size_t)(c0 + rr) * ld + c0 + cc] = sm.Dk[rr][cc];
+                    if (want_inv) Ub[(size_t)(c0 + rr) * ld + c0 + cc] = (cc >= rr) ? sm.Xk[cc][rr] : 0.0;
+                }
+            }
+            // ---- triangular solve as GEMM: out^T[ct] = sum_{ct' <= ct} Xk[ct, ct'] acc^T[ct'], then store
+            if (active && !(pass == 0 && wblk == 0)) {
+                double *Out = isM ? Lb : Ub;
+#pragma unroll
+                for (int ct = 3; ct >= 0; ct--) {
+                    v4d o[2];
+                    o[0] = (v4d){0.0, 0.0, 0.0, 0.0};
+                    o[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int cp = 0; cp <= ct; cp++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            double a = sm.Xk[16 * ct + li][16 * cp + 4 * r + g];
+#pragma unroll
+                            for (int u = 0; u < 2; u++) o[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[cp][u][r], o[u], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) Out[(size_t)(row0 + 16 * u + li) * ld + c0 + 16 * ct + 4 * r + g] = o[u][r];
+                }
+            }
+            __syncthreads();   // stores of this step visible to the whole workgroup before the next history read
+        }
+    }
+    return true;
+}
+
+// grid = nbatch, block = 1024
+__global__ void __launch_bounds__(CI_THREADS) k_cholinv(MedgpDev L, int want_inv) {
+    __shared__ CholInvSmem sm;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (L.status[b] < 0) return;
+    const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64);
+    int count = 0;
+    while (true) {
+        if (cholinv_attempt(L, b, slot, n, want_inv, sm)) break;
+        __syncthreads();
+        if (count >= 10) {   // ref: c_inference_exact.cpp:99,109-111
+            if (tid == 0) L.status[b] = -1;
+            return;
+        }
+        count++;
+        reassemble_wg(L, b, slot, n, npad, count);
+    }
+    __syncthreads();
+    const double *zz = L.z + (size_t)b * ld;
+    // quad = z^T z (fixed-order tree)
+    {
+        double s = 0.0;
+        for (int i = tid; i < npad; i += CI_THREADS) s += zz[i] * zz[i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if ((tid & 63) == 0) sm.red[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double q = 0.0;
+            for (int w = 0; w < CI_THREADS / 64; w++) q += sm.red[w];
+            L.status[b] = count;
+            L.scal[b * 4 + 0] = sm.logdet;
+            L.scal[b * 4 + 1] = q;
+        }
+    }
+    // alpha = L^-T z = U z : one wave per row, fixed-order shuffle tree
+    if (want_inv) {
+        const double *Ub = L.Linv + (size_t)b * ld * ld;
+        double *alpha = L.alpha + (size_t)b * ld;
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int r = wave; r < npad; r += CI_THREADS / 64) {
+            double s = 0.0;
+            for (int c = (r & ~63) + lane; c < npad; c += 64) s += Ub[(size_t)r * ld + c] * zz[c];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+            if (lane == 0) alpha[r] = s;
+        }
+    }
+}

@@ -291,11 +291,12 @@ __global__ void __launch_bounds__(256) k_potrf_v0(MedgpDev L) {
 }
 
 // ------------------------------------------------------------------------------------------
-// stage 3: X = L^-1 (lower) by forward substitution, one thread per column; alpha = X^T z.
+// stage 3 (v0 fallback): L^-1 by forward substitution, one thread per column; alpha = L^-T z.
 //   ref: c_inference_exact.cpp:124-143 (spotrs, strtri)
-// Rows/cols in [np16, npad64) are identity padding.  Entries above the diagonal are NOT written
-// (consumers mask k < i).
+// Stored like k_cholinv does: Linv holds U = L^-T (upper, row-major), (L^-1)[i][j] = U[j][i].
+// Rows/cols in [np16, npad64) are identity padding.
 // ------------------------------------------------------------------------------------------
+#define XU(i, j) X[(size_t)(j) * ld + (i)]
 __global__ void __launch_bounds__(256) k_trtri_v0(MedgpDev L) {
     const int b = blockIdx.x;
     if (L.status[b] < 0) return;
@@ -307,47 +308,49 @@ __global__ void __launch_bounds__(256) k_trtri_v0(MedgpDev L) {
     const int lane = threadIdx.x & 63;
     for (int j = threadIdx.x; j < npad; j += blockDim.x) {
         const int jw = j - lane;   // first column of this wave (uniform)
+        for (int i = (j & ~63); i < j; i++) XU(i, j) = 0.0;   // zero the strictly-lower part of U's diagonal block
         if (jw >= np) {            // whole wave in the identity padding
-            for (int i = j; i < npad; i++) X[(size_t)i * ld + j] = (i == j) ? 1.0 : 0.0;
+            for (int i = j; i < npad; i++) XU(i, j) = (i == j) ? 1.0 : 0.0;
             alpha[j] = 0.0;
             continue;
         }
         const bool real = j < np;
-        if (real) X[(size_t)j * ld + j] = 1.0 / Lm[(size_t)j * ld + j];
+        if (real) XU(j, j) = 1.0 / Lm[(size_t)j * ld + j];
         for (int i = jw + 1; i < np; i++) {
             double s = 0.0;
             const double *li = Lm + (size_t)i * ld;
             for (int k = jw; k < i; k++) {
-                double xv = (real && k >= j) ? X[(size_t)k * ld + j] : 0.0;
+                double xv = (real && k >= j) ? XU(k, j) : 0.0;
                 s += li[k] * xv;
             }
-            if (real && i > j) X[(size_t)i * ld + j] = -s / li[i];
+            if (real && i > j) XU(i, j) = -s / li[i];
         }
         if (real) {
-            for (int i = np; i < npad; i++) X[(size_t)i * ld + j] = 0.0;
+            for (int i = np; i < npad; i++) XU(i, j) = 0.0;
             double a = 0.0;
-            for (int i = j; i < np; i++) a += X[(size_t)i * ld + j] * zz[i];
+            for (int i = j; i < np; i++) a += XU(i, j) * zz[i];
             alpha[j] = a;
         } else {
-            for (int i = j; i < npad; i++) X[(size_t)i * ld + j] = (i == j) ? 1.0 : 0.0;
+            for (int i = j; i < npad; i++) XU(i, j) = (i == j) ? 1.0 : 0.0;
             alpha[j] = 0.0;
         }
     }
 }
+#undef XU
 
 // ------------------------------------------------------------------------------------------
-// stage 4: W = L^-T L^-1 - alpha alpha^T, lower 64x64 tiles, written over the (dead) L buffer
+// stage 4: W = L^-T L^-1 - alpha alpha^T = U U^T - alpha alpha^T, lower 64x64 tiles, written over the (dead) L buffer
 //   ref: c_inference_exact.cpp:168-172
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_lauum_v0(MedgpDev L) {
     __shared__ double Ai[16][64], Aj[16][64];
     const int b = blockIdx.y;
     if (L.status[b] < 0) return;
-    const int slot = L.bslot[b], n = L.pn[slot], np = medgp_roundup(n, 16), nt = medgp_roundup(n, 64) / 64, ld = L.ldn;
+    const int slot = L.bslot[b], n = L.pn[slot], np = medgp_roundup(n, 64), nt = np / 64, ld = L.ldn;
     int I, J;
     tile_decode(blockIdx.x, I, J);
     if (I >= nt) return;
-    const double *X = L.Linv + (size_t)b * ld * ld;
+    const double *U = L.Linv + (size_t)b * ld * ld;   // U[i][k] = (L^-1)[k][i]
     const double *alpha = L.alpha + (size_t)b * ld;
     double *W = L.Kmat + (size_t)b * ld * ld;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
@@ -359,12 +362,13 @@ __global__ void __launch_bounds__(256) k_lauum_v0(MedgpDev L) {
         for (int bb = 0; bb < 4; bb++) acc[a][bb] = 0.0;
     for (int kc = i0; kc < np; kc += 16) {
         {
-            int kk = tid >> 4, c4 = (tid & 15) * 4, k = kc + kk;
+            int rr = tid >> 2, k4 = (tid & 3) * 4;
+            int ii = i0 + rr, jj = j0 + rr;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                int ii = i0 + c4 + u, jj = j0 + c4 + u;
-                Ai[kk][c4 + u] = (k < np && k >= ii) ? X[(size_t)k * ld + ii] : 0.0;
-                Aj[kk][c4 + u] = (k < np && k >= jj) ? X[(size_t)k * ld + jj] : 0.0;
+                int k = kc + k4 + u;
+                Ai[k4 + u][rr] = (k < np && k >= ii) ? U[(size_t)ii * ld + k] : 0.0;
+                Aj[k4 + u][rr] = (k < np && k >= jj) ? U[(size_t)jj * ld + k] : 0.0;
             }
         }
         __syncthreads();
@@ -603,10 +607,9 @@ __global__ void __launch_bounds__(256) k_predict_v0(MedgpDev L, int b, int nstar
     const double mval = red[0];
     __syncthreads();
     double qv = 0.0;
-    for (int i = tid; i < n; i += nt) {
+    for (int i = tid; i < n; i += nt) {   // v_i = sum_{k<=i} (L^-1)[i][k] k*_k, (L^-1)[i][k] = U[k][i]
         double s = 0.0;
-        const double *xi = X + (size_t)i * ld;
-        for (int k = 0; k <= i; k++) s += xi[k] * ks[k];
+        for (int k = 0; k <= i; k++) s += X[(size_t)k * ld + i] * ks[k];
         qv += s * s;
     }
     red[tid] = qv;

@@ -4,19 +4,21 @@
 #include "../../include/medgp_hip.h"
 #include "medgp_dev.h"
 #include "kernels_v0.h"
+#include "kernels_cholinv.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 namespace {
 
-enum KernelId { KID_PREP = 0, KID_ASSEMBLE, KID_POTRF, KID_TRTRI, KID_LAUUM, KID_GRADBINS, KID_EPILOGUE, KID_PREDICT, KID_COUNT };
-const char *const kKernelNames[KID_COUNT] = {"k_prep", "k_assemble", "k_potrf", "k_trtri", "k_lauum", "k_gradbins", "k_epilogue", "k_predict"};
+enum KernelId { KID_PREP = 0, KID_ASSEMBLE, KID_POTRF, KID_TRTRI, KID_CHOLINV, KID_LAUUM, KID_GRADBINS, KID_EPILOGUE, KID_PREDICT, KID_COUNT };
+const char *const kKernelNames[KID_COUNT] = {"k_prep", "k_assemble", "k_potrf", "k_trtri", "k_cholinv", "k_lauum", "k_gradbins", "k_epilogue", "k_predict"};
 
 std::string g_create_error;
 
@@ -52,6 +54,7 @@ struct medgp_ctx {
     int pred_cap = 0;
     // profiling
     bool profiling = false;
+    bool use_v0 = false;      // MEDGP_V0=1: baseline kernels (debug / A-B parity)
     std::vector<EvPair> events;
     double prof_ms[KID_COUNT] = {0};
     int64_t prof_n[KID_COUNT] = {0};
@@ -162,9 +165,13 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
     const int nt64 = medgp_roundup(std::max(max_n, 1), 64) / 64;
     { Launcher l(c, KID_PREP); hipLaunchKernelGGL(k_prep, dim3(nbatch), dim3(256), 0, c->stream, L, theta_dev); }
     { Launcher l(c, KID_ASSEMBLE); hipLaunchKernelGGL(k_assemble_v0, dim3(tri(nt64), nbatch), dim3(256), 0, c->stream, L); }
-    { Launcher l(c, KID_POTRF); hipLaunchKernelGGL(k_potrf_v0, dim3(nbatch), dim3(256), 0, c->stream, L); }
-    if (flag_grad || need_inverse) {
-        { Launcher l(c, KID_TRTRI); hipLaunchKernelGGL(k_trtri_v0, dim3(nbatch), dim3(256), 0, c->stream, L); }
+    const bool inv = flag_grad || need_inverse;
+    if (c->use_v0) {
+        { Launcher l(c, KID_POTRF); hipLaunchKernelGGL(k_potrf_v0, dim3(nbatch), dim3(256), 0, c->stream, L); }
+        if (inv) { Launcher l(c, KID_TRTRI); hipLaunchKernelGGL(k_trtri_v0, dim3(nbatch), dim3(256), 0, c->stream, L); }
+    } else {
+        Launcher l(c, KID_CHOLINV);
+        hipLaunchKernelGGL(k_cholinv, dim3(nbatch), dim3(CI_THREADS), 0, c->stream, L, (inv ? 1 : 0) | (getenv("MEDGP_DBG_SKIPDIAG") ? 2 : 0));
     }
     if (flag_grad) {
         { Launcher l(c, KID_LAUUM); hipLaunchKernelGGL(k_lauum_v0, dim3(tri(nt64), nbatch), dim3(256), 0, c->stream, L); }
@@ -214,6 +221,7 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
         return fail(nullptr, MEDGP_ERR_HIP, "cannot initialise device %d", device);
     }
     c->stream = c->own_stream;
+    { const char *e = getenv("MEDGP_V0"); c->use_v0 = e && e[0] == '1'; }
     *out = c;
     return MEDGP_OK;
 }
@@ -438,7 +446,8 @@ int medgp_get_factor(medgp_ctx *c, int b, float *alpha, float *linv, float *beta
         std::vector<double> hx((size_t)n * ld);
         HIPCHK(c, hipMemcpy(hx.data(), c->dev.Linv + (size_t)b * ld * ld, sizeof(double) * n * ld, hipMemcpyDeviceToHost));
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) linv[(size_t)i * n + j] = (j <= i) ? (float)hx[(size_t)i * ld + j] : 0.0f;   // ref: c_inference_exact.cpp:139-143
+            for (int j = 0; j < n; j++)   // device holds U = L^-T: (L^-1)[i][j] = U[j][i]; strict upper zeroed as ref c_inference_exact.cpp:139-143
+                linv[(size_t)i * n + j] = (j <= i) ? (float)hx[(size_t)j * ld + i] : 0.0f;
     }
     return MEDGP_OK;
 }
