@@ -45,6 +45,14 @@ def load():
     if not os.path.exists(p):
         raise MedgpError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(make -C medgp_amd/csrc). medgp_amd has no CPU fallback.")
+    # Share ONE HIP runtime per process: torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's);
+    # whichever is loaded first is used by both, and a torch initialised after a foreign runtime can come
+    # up with "No HIP GPUs are available".  So when torch is importable, let it load first.  (The C ABI
+    # itself has no torch dependency; C/C++ hosts are unaffected.)
+    try:
+        import torch  # noqa: F401
+    except Exception:   # pragma: no cover
+        pass
     lib = C.CDLL(p)
     vp, i32p, dp, fp, u8p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
     lib.medgp_abi_version.restype = C.c_int

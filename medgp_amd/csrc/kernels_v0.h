@@ -463,7 +463,7 @@ __device__ inline void prior_apply(const MedgpPrior &p, double hv, double pi, bo
 
 __device__ inline double sym_get(const double *S, int D, int d, int e) { return d >= e ? S[d * D + e] : S[e * D + d]; }
 
-__global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__restrict__ theta, int flag_grad,
+__global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__restrict__ theta, int flag_grad, int from_slab,
                                                   double *__restrict__ nlml_out, double *__restrict__ grad_out,
                                                   int *__restrict__ status_out) {
     __shared__ double red[256];
@@ -483,7 +483,33 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
     const double *B = hyp + hyp_off_B(L);
     const double *S = L.S + (size_t)b * Q * D * D, *SM = L.SM + (size_t)b * Q * D * D, *SV = L.SV + (size_t)b * Q * D * D;
     const int *seg = L.pseg + (size_t)slot * (D + 1);
-    const double *W = L.Kmat + (size_t)b * ld * ld;
+    // diag(W): k_wgrad exports it; the v0 path keeps the full W in the Kmat buffer
+    const double *Wd = from_slab ? L.wdiag + (size_t)b * ld : L.Kmat + (size_t)b * ld * ld;
+    const size_t wds = from_slab ? 1 : (size_t)ld + 1;
+    if (flag_grad && from_slab) {
+        // add the pieces written by k_wgrad in a fixed order: rows pieces outer, column pieces inner
+        const int *roff = L.proff + (size_t)slot * (D + 1), *coff = L.pcoff + (size_t)slot * (D + 1);
+        const double *slab = L.slab + (size_t)b * L.slab_stride;
+        const int nbins = D * (D + 1) / 2;
+        for (int idx = tid; idx < 3 * Q * nbins; idx += nt) {
+            const int pq = idx / nbins;          // plane * Q + q
+            int d, e;
+            tile_decode(idx - pq * nbins, d, e);
+            const double *sl = slab + (size_t)pq * L.slab_R * L.slab_C;
+            double s = 0.0;
+            for (int rs = roff[d]; rs < roff[d + 1]; rs++) {
+                const int It = (seg[d] / 16 + (rs - roff[d])) / 4;
+                for (int cs = coff[e]; cs < coff[e + 1]; cs++) {
+                    const int Jt = seg[e] / 64 + (cs - coff[e]);
+                    if (Jt <= It) s += sl[(size_t)rs * L.slab_C + cs];
+                }
+            }
+            const int pl = pq / Q, q = pq - pl * Q;
+            double *dst = (pl == 0 ? L.S : (pl == 1 ? L.SM : L.SV)) + (size_t)b * Q * D * D;
+            dst[(size_t)q * D * D + d * D + e] = s;
+        }
+        __syncthreads();
+    }
     const MedgpPrior *pr = L.prior_on[slot] ? L.prior + (size_t)slot * H : nullptr;
     double lp_local = 0.0;
     for (int h = tid; h < H; h += nt) {
@@ -493,7 +519,7 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
                 hv = exp(th[h]);
                 if (flag_grad) {
                     double s = 0.0;
-                    for (int i = seg[h]; i < seg[h + 1]; i++) s += hv * hv * W[(size_t)i * ld + i];
+                    for (int i = seg[h]; i < seg[h + 1]; i++) s += hv * hv * Wd[(size_t)i * wds];
                     gv = s;   // ref: c_inference_exact.cpp:194-202
                 }
             } else {
@@ -532,7 +558,7 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
             if (flag_grad) {
                 if (h == 0) {
                     double s = 0.0;
-                    for (int i = 0; i < n; i++) s += hv * hv * W[(size_t)i * ld + i];
+                    for (int i = 0; i < n; i++) s += hv * hv * Wd[(size_t)i * wds];
                     gv = s;
                 } else {
                     int hc = h - 1, mode = hc / Q, q = hc - mode * Q;
@@ -545,7 +571,7 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
             if (flag_grad) {
                 if (h == 0) {
                     double s = 0.0;
-                    for (int i = 0; i < n; i++) s += hv * hv * W[(size_t)i * ld + i];
+                    for (int i = 0; i < n; i++) s += hv * hv * Wd[(size_t)i * wds];
                     gv = s;
                 } else if (h == 1) gv = -0.5 * B[0] * SV[0];   // d/dlog l = -d/dlog v  (ref: c_kernel_SE.cpp:106-118)
                 else gv = B[0] * S[0];                         // ref: c_kernel_SE.cpp:120-131

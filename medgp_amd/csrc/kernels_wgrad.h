@@ -1,0 +1,179 @@
+// kernels_wgrad.h -- fused  W = K^-1 - alpha alpha^T  (never written to HBM) + gradient block reductions.
+//
+// Replaces the reference's  Q = L^-T L^-1 - alpha alpha^T  (two sgemm, ref: inference/c_inference_exact.cpp:168-172)
+// and the per-hyper loop of c_kernel_LMC_SM::compute_self_gradients (ref: kernel/c_kernel_LMC_SM.cpp:198-327),
+// regrouped into block sums:
+//     S_q [d,e] = sum_{i in d, j in e} W_ij k_q(t_i - t_j)
+//     SM_q[d,e] = sum W_ij * ( -(w_q dt) sin(w_q dt) E_q )         (d k_q / d log mu_q,  ref :379-384)
+//     SV_q[d,e] = sum W_ij * ( -2 c_q dt^2 k_q )                   (d k_q / d log v_q,   ref :385-391)
+// One workgroup (4 waves) per lower 64x64 tile (I, J) of one patient:
+//   phase 1  W tile = U[I rows] U[J rows]^T on fp64 MFMA (U = L^-T from k_cholinv; k runs over columns >= 64 I);
+//            the J-row fragments are staged through LDS (shared by the 4 waves), the I-row fragments stream
+//            from HBM with 16-byte loads.
+//   phase 2  tile -> LDS (aliases the staging buffers).
+//   phase 3  lane = column j, wave = 16-row group: per element one fp64 exp per mixture component (cos/sin of the
+//            time difference come from the per-observation tables by the angle-difference identity).
+//            Observations are grouped by output, so the output of the row changes rarely: running sums are
+//            flushed at each change and reduced over the column segments in a FIXED order -> bitwise
+//            reproducible; every (16-row piece of d) x (column tile piece of e) owns one slab entry, written
+//            exactly once (no atomics).  k_epilogue adds the pieces in fixed order.
+#pragma once
+#include "medgp_dev.h"
+
+#define WG_KC 32
+#define WG_THREADS 256
+
+template <int QT>
+__global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
+    // staging buffers (phase 1) and the W tile (phase 2/3) share storage
+    __shared__ __attribute__((aligned(16))) double smem[2 * 64 * (WG_KC + 2)];
+    __shared__ double Fl[4][64];
+    typedef double (*BsT)[64][WG_KC + 2];
+    BsT Bs = (BsT)smem;                       // Bs[2][64][34]
+    double (*Ws)[66] = (double (*)[66])smem;   // Ws[64][66]  (4224 <= 4352 doubles)
+
+    const int b = blockIdx.y;
+    if (L.status[b] < 0) return;
+    const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
+    int I, J;
+    tile_decode(blockIdx.x, I, J);
+    if (I >= nb) return;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double *U = L.Linv + (size_t)b * ld * ld;
+
+    // ---------------- phase 1: acc[ct] (rows 16w.. of block I, cols 16ct.. of block J)
+    v4d acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) acc[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
+    {
+        const int k0 = 64 * I, nch = (npad - k0) / WG_KC;
+        const double *Arow = U + (size_t)(64 * I + 16 * w + li) * ld + k0 + 2 * g;
+        const int srow = tid >> 2, scg = (tid & 3) * 8;
+        const double *Bsrc = U + (size_t)(64 * J + srow) * ld + k0 + scg;
+        v2d bst[4], an[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) bst[u] = *(const v2d *)(Bsrc + 2 * u);
+#pragma unroll
+        for (int h = 0; h < 4; h++) an[h] = *(const v2d *)(Arow + 8 * h);
+#pragma unroll
+        for (int u = 0; u < 4; u++) *(v2d *)&Bs[0][srow][scg + 2 * u] = bst[u];
+        __syncthreads();
+        for (int c = 0; c < nch; c++) {
+            const int buf = c & 1;
+            v2d ac[4];
+#pragma unroll
+            for (int h = 0; h < 4; h++) ac[h] = an[h];
+            if (c + 1 < nch) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) bst[u] = *(const v2d *)(Bsrc + (c + 1) * WG_KC + 2 * u);
+#pragma unroll
+                for (int h = 0; h < 4; h++) an[h] = *(const v2d *)(Arow + (c + 1) * WG_KC + 8 * h);
+            }
+#pragma unroll
+            for (int h = 0; h < 4; h++)
+#pragma unroll
+                for (int ct = 0; ct < 4; ct++) {
+                    const v2d bf = *(const v2d *)&Bs[buf][16 * ct + li][8 * h + 2 * g];
+#pragma unroll
+                    for (int s = 0; s < 2; s++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[h][s], bf[s], acc[ct], 0, 0, 0);
+                }
+            if (c + 1 < nch) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) *(v2d *)&Bs[buf ^ 1][srow][scg + 2 * u] = bst[u];
+            }
+            __syncthreads();
+        }
+    }
+    // ---------------- phase 2: W tile -> LDS (all waves are past the last staging read: barrier above)
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) Ws[16 * w + 4 * r + g][16 * ct + li] = acc[ct][r];
+    __syncthreads();
+
+    // ---------------- phase 3
+    const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
+    const double *t = L.pt + (size_t)slot * ld;
+    const int *meta = L.pmeta + (size_t)slot * ld;
+    const double *alpha = L.alpha + (size_t)b * ld;
+    const int *seg = L.pseg + (size_t)slot * (L.D + 1);
+    const int *roff = L.proff + (size_t)slot * (L.D + 1), *coff = L.pcoff + (size_t)slot * (L.D + 1);
+    const double *csb = L.cs + (size_t)b * QT * ld, *snb = L.sn + (size_t)b * QT * ld;
+    double *slab = L.slab + (size_t)b * L.slab_stride;
+    const int Rmax = L.slab_R, Cmax = L.slab_C;
+
+    double wq[QT], cq[QT];
+#pragma unroll
+    for (int q = 0; q < QT; q++) { wq[q] = hyp[hyp_off_w(L) + q]; cq[q] = hyp[hyp_off_c(L) + q]; }
+    // column constants of this lane
+    const int j = 64 * J + lane;
+    const bool jv = j < n;
+    const double tj = t[j], aj = alpha[j];
+    const int mj = jv ? meta[j] : -1;
+    double csj[QT], snj[QT];
+#pragma unroll
+    for (int q = 0; q < QT; q++) { csj[q] = csb[q * ld + j]; snj[q] = snb[q * ld + j]; }
+    // column segments inside the tile: leader lanes and their segment ends
+    const int mprev = __shfl_up(mj, 1);
+    const bool leader = (lane == 0) || (mj != mprev);
+    const unsigned long long lmask = __ballot(leader);
+    int segend;
+    {
+        unsigned long long above = (lane == 63) ? 0ull : (lmask >> (lane + 1));
+        segend = above ? (lane + 1 + __builtin_ctzll(above)) : 64;
+    }
+    const int cslot = (mj >= 0) ? coff[mj] + (J - seg[mj] / 64) : 0;
+    const int rg = 4 * I + w;   // global 16-row group of this wave
+
+    double sS[QT], sM[QT], sV[QT];
+#pragma unroll
+    for (int q = 0; q < QT; q++) { sS[q] = 0.0; sM[q] = 0.0; sV[q] = 0.0; }
+    double *fl = Fl[w];
+    int mcur = -2;
+    for (int rr = 0; rr <= 16; rr++) {
+        const int i = 64 * I + 16 * w + rr;
+        int mi = -1;
+        if (rr < 16 && i < n) mi = meta[i];          // wave-uniform
+        if (mi != mcur) {
+            // flush the running sums of row output mcur (skip padding / initial state)
+            if (mcur >= 0) {
+                const int rslot = roff[mcur] + (rg - seg[mcur] / 16);
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+                    for (int q = 0; q < QT; q++) {
+                        fl[lane] = (pl == 0) ? sS[q] : (pl == 1 ? sM[q] : sV[q]);
+                        __builtin_amdgcn_wave_barrier();
+                        if (leader && mj >= 0) {
+                            double s = 0.0;
+                            for (int c2 = lane; c2 < segend; c2++) s += fl[c2];
+                            slab[((size_t)(pl * QT + q) * Rmax + rslot) * Cmax + cslot] = s;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < QT; q++) { sS[q] = 0.0; sM[q] = 0.0; sV[q] = 0.0; }
+            mcur = mi;
+        }
+        if (rr == 16 || mi < 0) continue;
+        const double ti = t[i], ai = alpha[i];
+        double wv = Ws[16 * w + rr][lane] - ai * aj;
+        if (I == J && j == i) L.wdiag[(size_t)b * ld + i] = wv;   // noise gradient needs diag(W)
+        const bool valid = jv && (j <= i);
+        wv = valid ? ((mi == mj && j < i) ? 2.0 * wv : wv) : 0.0;
+        const double dt = ti - tj, dd = dt * dt;
+#pragma unroll
+        for (int q = 0; q < QT; q++) {
+            const double ci = csb[q * ld + i], si = snb[q * ld + i];   // wave-uniform loads
+            const double E = exp(-cq[q] * dd);
+            const double cd = ci * csj[q] + si * snj[q];
+            const double sd = si * csj[q] - ci * snj[q];
+            const double k = cd * E;
+            sS[q] += wv * k;
+            sM[q] += wv * (-(wq[q] * dt * sd) * E);
+            sV[q] += wv * (-2.0 * cq[q] * dd * k);
+        }
+    }
+}

@@ -5,6 +5,7 @@
 #include "medgp_dev.h"
 #include "kernels_v0.h"
 #include "kernels_cholinv.h"
+#include "kernels_wgrad.h"
 
 #include <algorithm>
 #include <cmath>
@@ -17,8 +18,8 @@
 
 namespace {
 
-enum KernelId { KID_PREP = 0, KID_ASSEMBLE, KID_POTRF, KID_TRTRI, KID_CHOLINV, KID_LAUUM, KID_GRADBINS, KID_EPILOGUE, KID_PREDICT, KID_COUNT };
-const char *const kKernelNames[KID_COUNT] = {"k_prep", "k_assemble", "k_potrf", "k_trtri", "k_cholinv", "k_lauum", "k_gradbins", "k_epilogue", "k_predict"};
+enum KernelId { KID_PREP = 0, KID_ASSEMBLE, KID_POTRF, KID_TRTRI, KID_CHOLINV, KID_LAUUM, KID_GRADBINS, KID_WGRAD, KID_EPILOGUE, KID_PREDICT, KID_COUNT };
+const char *const kKernelNames[KID_COUNT] = {"k_prep", "k_assemble", "k_potrf", "k_trtri", "k_cholinv", "k_lauum", "k_gradbins", "k_wgrad", "k_epilogue", "k_predict"};
 
 std::string g_create_error;
 
@@ -35,6 +36,7 @@ struct medgp_ctx {
     MedgpDev dev{};
     // device allocations
     std::vector<void *> allocs;
+    int *d_proff = nullptr, *d_pcoff = nullptr;
     int *d_pn = nullptr, *d_pmeta = nullptr, *d_pseg = nullptr, *d_bslot = nullptr, *d_status = nullptr;
     double *d_pt = nullptr, *d_py = nullptr;
     MedgpPrior *d_prior = nullptr;
@@ -117,7 +119,8 @@ struct Launcher {
     ~Launcher() {
         if (c->profiling) {
             (void)hipEventRecord(b, c->stream);
-            c->events.push_back({kid, a, b});
+            if (kid >= 0) c->events.push_back({kid, a, b});
+            else { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
         }
     }
 };
@@ -173,14 +176,32 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
         Launcher l(c, KID_CHOLINV);
         hipLaunchKernelGGL(k_cholinv, dim3(nbatch), dim3(CI_THREADS), 0, c->stream, L, (inv ? 1 : 0) | (getenv("MEDGP_DBG_SKIPDIAG") ? 2 : 0));
     }
+    int from_slab = 0;
     if (flag_grad) {
-        { Launcher l(c, KID_LAUUM); hipLaunchKernelGGL(k_lauum_v0, dim3(tri(nt64), nbatch), dim3(256), 0, c->stream, L); }
-        const int nbins = L.Q * tri(L.D);
-        { Launcher l(c, KID_GRADBINS); hipLaunchKernelGGL(k_gradbins_v0, dim3((nbins + 255) / 256, nbatch), dim3(256), 0, c->stream, L); }
+        const dim3 tg(tri(nt64), nbatch), tb(WG_THREADS);
+        from_slab = 1;
+        Launcher *lw = new Launcher(c, KID_WGRAD);
+        switch (c->use_v0 ? 0 : L.Q) {
+        case 1: hipLaunchKernelGGL(k_wgrad<1>, tg, tb, 0, c->stream, L); break;
+        case 2: hipLaunchKernelGGL(k_wgrad<2>, tg, tb, 0, c->stream, L); break;
+        case 3: hipLaunchKernelGGL(k_wgrad<3>, tg, tb, 0, c->stream, L); break;
+        case 4: hipLaunchKernelGGL(k_wgrad<4>, tg, tb, 0, c->stream, L); break;
+        case 5: hipLaunchKernelGGL(k_wgrad<5>, tg, tb, 0, c->stream, L); break;
+        case 6: hipLaunchKernelGGL(k_wgrad<6>, tg, tb, 0, c->stream, L); break;
+        case 7: hipLaunchKernelGGL(k_wgrad<7>, tg, tb, 0, c->stream, L); break;
+        case 8: hipLaunchKernelGGL(k_wgrad<8>, tg, tb, 0, c->stream, L); break;
+        default: from_slab = 0; break;   // Q > 8 (or MEDGP_V0): generic kernels below
+        }
+        if (from_slab) delete lw; else { lw->kid = -1; delete lw; }
+        if (!from_slab) {
+            { Launcher l(c, KID_LAUUM); hipLaunchKernelGGL(k_lauum_v0, dim3(tri(nt64), nbatch), dim3(256), 0, c->stream, L); }
+            const int nbins = L.Q * tri(L.D);
+            { Launcher l(c, KID_GRADBINS); hipLaunchKernelGGL(k_gradbins_v0, dim3((nbins + 255) / 256, nbatch), dim3(256), 0, c->stream, L); }
+        }
     }
     if (nlml_dev) {
         Launcher l(c, KID_EPILOGUE);
-        hipLaunchKernelGGL(k_epilogue, dim3(nbatch), dim3(256), 0, c->stream, L, theta_dev, flag_grad, nlml_dev, grad_dev, (int *)status_dev);
+        hipLaunchKernelGGL(k_epilogue, dim3(nbatch), dim3(256), 0, c->stream, L, theta_dev, flag_grad, from_slab, nlml_dev, grad_dev, (int *)status_dev);
     }
     HIPCHK(c, hipGetLastError());
     return MEDGP_OK;
@@ -276,6 +297,8 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     if ((rc = dalloc(c, &c->d_py, S * ldn))) return rc;
     if ((rc = dalloc(c, &c->d_pmeta, S * ldn))) return rc;
     if ((rc = dalloc(c, &c->d_pseg, S * (D + 1)))) return rc;
+    if ((rc = dalloc(c, &c->d_proff, S * (D + 1)))) return rc;
+    if ((rc = dalloc(c, &c->d_pcoff, S * (D + 1)))) return rc;
     if ((rc = dalloc(c, &c->d_prior, S * H))) return rc;
     if ((rc = dalloc(c, &c->d_prior_on, S))) return rc;
     if ((rc = dalloc(c, &c->d_bslot, B))) return rc;
@@ -289,7 +312,12 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     L.ldn = ldn; L.max_slots = max_slots; L.max_batch = max_batch;
     L.hyp_stride = (int)(D + Q * D * D + 2 * Q);
     L.pi = c->pi;
-    double *hyp, *cs, *sn, *Kmat, *Linv, *z, *alpha, *scal, *Sb, *SMb, *SVb;
+    double *hyp, *cs, *sn, *Kmat, *Linv, *z, *alpha, *scal, *Sb, *SMb, *SVb, *slab, *wdiag;
+    L.slab_R = ldn / 16 + (int)D;
+    L.slab_C = ldn / 64 + (int)D;
+    L.slab_stride = (size_t)3 * Q * L.slab_R * L.slab_C;
+    if ((rc = dalloc(c, &slab, B * L.slab_stride))) return rc;
+    if ((rc = dalloc(c, &wdiag, B * ldn))) return rc;
     if ((rc = dalloc(c, &hyp, B * L.hyp_stride))) return rc;
     if ((rc = dalloc(c, &cs, B * Q * ldn))) return rc;
     if ((rc = dalloc(c, &sn, B * Q * ldn))) return rc;
@@ -302,6 +330,7 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     if ((rc = dalloc(c, &SMb, B * Q * D * D))) return rc;
     if ((rc = dalloc(c, &SVb, B * Q * D * D))) return rc;
     L.pn = c->d_pn; L.pt = c->d_pt; L.py = c->d_py; L.pmeta = c->d_pmeta; L.pseg = c->d_pseg;
+    L.proff = c->d_proff; L.pcoff = c->d_pcoff; L.slab = slab; L.wdiag = wdiag;
     L.prior = c->d_prior; L.prior_on = c->d_prior_on; L.bslot = c->d_bslot;
     L.hyp = hyp; L.cs = cs; L.sn = sn; L.Kmat = Kmat; L.Linv = Linv; L.z = z; L.alpha = alpha; L.scal = scal;
     L.status = c->d_status; L.S = Sb; L.SM = SMb; L.SV = SVb;
@@ -354,6 +383,15 @@ int medgp_set_patient(medgp_ctx *c, int slot, int n, const int32_t *meta, const 
     HIPCHK(c, hipMemcpyAsync(c->d_py + (size_t)slot * ldn, hy.data(), sizeof(double) * ldn, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_pmeta + (size_t)slot * ldn, hm.data(), sizeof(int) * ldn, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_pseg + (size_t)slot * (D + 1), seg.data(), sizeof(int) * (D + 1), hipMemcpyHostToDevice, c->stream));
+    // slab slots of k_wgrad: 16-row pieces and 64-column pieces each output's segment intersects
+    std::vector<int> roff(D + 1, 0), coff(D + 1, 0);
+    for (int d = 0; d < D; d++) {
+        const int a = seg[d], e = seg[d + 1];
+        roff[d + 1] = roff[d] + (e > a ? (e - 1) / 16 - a / 16 + 1 : 0);
+        coff[d + 1] = coff[d] + (e > a ? (e - 1) / 64 - a / 64 + 1 : 0);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_proff + (size_t)slot * (D + 1), roff.data(), sizeof(int) * (D + 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pcoff + (size_t)slot * (D + 1), coff.data(), sizeof(int) * (D + 1), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_pn + slot, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->h_n[slot] = n;

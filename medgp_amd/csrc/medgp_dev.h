@@ -31,6 +31,8 @@ struct MedgpDev {
     const double *pt, *py;   // [slot][ldn]
     const int *pmeta;        // [slot][ldn]
     const int *pseg;         // [slot][D+1]
+    const int *proff;        // [slot][D+1] prefix of 16-row pieces per output (slab row slots)
+    const int *pcoff;        // [slot][D+1] prefix of 64-column pieces per output (slab column slots)
     const MedgpPrior *prior; // [slot][H]
     const uint8_t *prior_on; // [slot]
     // batch
@@ -42,6 +44,10 @@ struct MedgpDev {
     double *scal;            // [batch][4]: logdet, quad, -, -
     int *status;             // [batch]
     double *S, *SM, *SV;     // [batch][Q*D*D]
+    double *slab;            // [batch][3][Q][slab_R][slab_C] piecewise block sums written by k_wgrad
+    double *wdiag;           // [batch][ldn] diag(W)
+    int slab_R, slab_C;
+    size_t slab_stride;
 };
 
 __host__ __device__ inline int medgp_roundup(int x, int m) { return (x + m - 1) / m * m; }
