@@ -1,0 +1,78 @@
+// kernels_assemble.h -- Gram assembly, tuned: one workgroup (4 waves) per lower 64x64 tile.
+//   K_ij = sum_q B_q[m_i,m_j] cos(w_q (t_i - t_j)) exp(-c_q (t_i - t_j)^2)  + [i == j] sigma^2_{m_i}
+//   ref: kernel/c_kernel_LMC_SM.cpp:152-196 (+ SE :72-89, SM :75-110), inference/c_inference_exact.cpp:88-92
+// lane = column j (its t, meta, cos/sin table entries stay in registers), wave = 16-row group (row constants are
+// wave-uniform scalar loads); one fp64 exp per (pair, component), no trigonometry in the pair loop; every
+// row is stored as one coalesced 512-byte segment.  Identity padding up to the next multiple of 64.
+#pragma once
+#include "medgp_dev.h"
+
+// exp(-x) for x >= 0, ~1e-15 relative: Cody-Waite reduction by ln2/1, degree-11 Taylor/Horner, v_ldexp_f64.
+// (results that underflow come out as 0, exactly what the envelope needs)
+__device__ __forceinline__ double exp_neg(double x) {
+    const double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    double y = -x;
+    double nf = rint(y * LOG2E);
+    double r = fma(-nf, LN2_HI, y);
+    r = fma(-nf, LN2_LO, r);
+    double p = 2.50521083854417187751e-08;            // 1/11!
+    p = fma(p, r, 2.75573192239858906526e-07);        // 1/10!
+    p = fma(p, r, 2.75573192239858906526e-06);        // 1/9!
+    p = fma(p, r, 2.48015873015873015873e-05);        // 1/8!
+    p = fma(p, r, 1.98412698412698412698e-04);        // 1/7!
+    p = fma(p, r, 1.38888888888888888889e-03);        // 1/6!
+    p = fma(p, r, 8.33333333333333333333e-03);        // 1/5!
+    p = fma(p, r, 4.16666666666666666667e-02);        // 1/4!
+    p = fma(p, r, 1.66666666666666666667e-01);        // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int n = (int)fmax(nf, -1100.0);
+    return ldexp(p, n);
+}
+
+template <int QT>
+__global__ void __launch_bounds__(256) k_assemble_t(MedgpDev L) {
+    const int b = blockIdx.y;
+    if (L.status[b] < 0) return;
+    const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
+    int I, J;
+    tile_decode(blockIdx.x, I, J);
+    if (I >= nb) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = L.D;
+    const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
+    const double *B = hyp + hyp_off_B(L);
+    const double *t = L.pt + (size_t)slot * ld;
+    const int *meta = L.pmeta + (size_t)slot * ld;
+    const double *csb = L.cs + (size_t)b * QT * ld, *snb = L.sn + (size_t)b * QT * ld;
+    double *K = L.Kmat + (size_t)b * ld * ld;
+    double cq[QT];
+#pragma unroll
+    for (int q = 0; q < QT; q++) cq[q] = hyp[hyp_off_c(L) + q];
+    const int j = 64 * J + lane;
+    const bool jv = j < n;
+    const double tj = t[j];
+    const int mj = meta[j];
+    double csj[QT], snj[QT];
+#pragma unroll
+    for (int q = 0; q < QT; q++) { csj[q] = csb[q * ld + j]; snj[q] = snb[q * ld + j]; }
+    for (int rr = 0; rr < 16; rr++) {
+        const int i = 64 * I + 16 * w + rr;          // wave-uniform
+        double v;
+        if (i < n) {
+            const double dt = t[i] - tj, dd = dt * dt;
+            const double *Brow = B + meta[i] * D + mj;
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < QT; q++) {
+                const double cd = csb[q * ld + i] * csj[q] + snb[q * ld + i] * snj[q];
+                acc += Brow[q * D * D] * (cd * exp_neg(cq[q] * dd));
+            }
+            if (i == j) acc += hyp[mj];
+            v = jv ? acc : 0.0;
+        } else v = (i == j) ? 1.0 : 0.0;
+        K[(size_t)i * ld + j] = v;
+    }
+}

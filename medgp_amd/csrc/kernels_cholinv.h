@@ -23,11 +23,13 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define CI_KC 16          // k-columns staged per barrier
-#define CI_THREADS 1024   // 16 waves: 8 blocks x 2 halves per pass
+#define CI_THREADS 1024   // largest workgroup (16 waves: 8 blocks x 2 halves per pass)
 
 struct CholInvSmem {
-    double Bs[2][64][CI_KC + 2];   // staged chunk of L[C_k rows][kc .. kc+16)
-    double Dk[64][66];             // diagonal block: in D, out L_kk (lower)
+    union {                            // never live at the same time: Bs during the history GEMM, Dk afterwards
+        double Bs[2][64][CI_KC + 2];   // staged chunk of L[C_k rows][kc .. kc+16)
+        double Dk[64][66];             // diagonal block: in D, out L_kk (lower)
+    };
     double Xk[64][66];             // L_kk^-1 (lower)
     double zacc[64];               // L[C_k, 0:64k] z[0:64k]
     double rhs[64];
@@ -124,7 +126,7 @@ __device__ inline bool diag16(double *T, double *X, double *rdl, int lane, doubl
 
 // Cholesky of the 64x64 block in sm.Dk (lower, in place) and its inverse into sm.Xk (lower), on ONE wave:
 // 16x16 tiles, diagonal tiles in registers (diag16), everything else as MFMA tile products out of LDS.
-__device__ inline void diag_factor_wave(CholInvSmem &sm, int lane) {
+__device__ __attribute__((noinline)) void diag_factor_wave(CholInvSmem &sm, int lane) {
     const int li = lane & 15, g = lane >> 4;
     double *D = &sm.Dk[0][0], *X = &sm.Xk[0][0];
 #define TD(s, t) (D + (16 * (s)) * CI_S + 16 * (t))
@@ -169,8 +171,7 @@ __device__ inline void diag_factor_wave(CholInvSmem &sm, int lane) {
             tile_st(TX(s2, t), -xs, li, g);
             __builtin_amdgcn_wave_barrier();
         }
-    // zero the strictly-upper tiles of X (consumers read whole 16x16 tiles only on/below the diagonal,
-    // but U_kk is exported from X with zeros)
+    // zero the strictly-upper tiles of X (U_kk is exported from X with zeros)
 #pragma unroll 1
     for (int t = 1; t < 4; t++)
         for (int s2 = 0; s2 < t; s2++) tile_st(TX(s2, t), zero4, li, g);
@@ -180,7 +181,13 @@ __device__ inline void diag_factor_wave(CholInvSmem &sm, int lane) {
 }
 
 // one factorisation attempt; returns false if a pivot failed
+template <int NW, int UPW>
 __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int want_inv, CholInvSmem &sm) {
+    constexpr int NT = NW * 64;          // threads
+    constexpr int RPW = 16 * UPW;        // rows per wave (UPW 16-row MFMA units)
+    constexpr int WPB = 64 / RPW;        // waves per 64-row block
+    constexpr int BP = NW / WPB;         // 64-row blocks per pass
+    static_assert(WPB == 1, "one wave owns a whole 64-row block");
     const int ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
     double *Lb = L.Kmat + (size_t)b * ld * ld;
     double *Ub = L.Linv + (size_t)b * ld * ld;
@@ -188,7 +195,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
     const double *y = L.py + (size_t)slot * ld;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, g = lane >> 4;
-    const int wblk = wave >> 1, whalf = wave & 1;
+    const int wblk = wave / WPB, wsub = wave % WPB;
 
     if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
     __syncthreads();
@@ -197,33 +204,44 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
         const int c0 = 64 * k;                       // first column of the panel
         const int nM = nb - k;                       // K-row blocks (first one is the diagonal block)
         const int ntot = nM + (want_inv ? k : 0);    // + U-row blocks
-        const int npass = (ntot + 7) / 8;
+        const int npass = (ntot + BP - 1) / BP;
         const int nch = c0 / CI_KC;                  // history chunks
         for (int pass = 0; pass < npass; pass++) {
-            const int bidx = pass * 8 + wblk;
+            const int bidx = pass * BP + wblk;
             const bool active = bidx < ntot;
             const bool isM = bidx < nM;
             const int rblk = isM ? (k + bidx) : (bidx - nM);           // row block of this wave
-            const int row0 = 64 * rblk + 32 * whalf;                   // first of my 32 rows
+            const int row0 = 64 * rblk + RPW * wsub;                   // first of my RPW rows
             const double *Hist = isM ? Lb : Ub;
             const int kstart = isM ? 0 : 64 * rblk;
             const int cfirst = kstart / CI_KC;
-            v4d acc[4][2];
+            // acc starts at -init (init = K block for K rows, 0 for U rows); the history GEMM adds P, so the
+            // panel value is  init - P = -acc  (the sign is folded into the operands that consume acc)
+            v4d acc[4][UPW];
 #pragma unroll
             for (int ct = 0; ct < 4; ct++)
 #pragma unroll
-                for (int u = 0; u < 2; u++) acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
+                for (int u = 0; u < UPW; u++) {
+                    acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
+                    if (active && isM) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[ct][u][r] = -Lb[(size_t)(row0 + 16 * u + li) * ld + c0 + 16 * ct + 4 * r + g];
+                    }
+                }
             double zsum = 0.0;
             // ---- GEMM over the history, B chunk (L[C_k rows]) staged through LDS, double buffered
             if (nch > 0) {
-                const int srow = tid >> 4, scol = tid & 15;
+                // staging: 64 x 16 doubles per chunk, NT threads -> 1024 / NT elements each
+                constexpr int SPT = 1024 / NT;
+                const int srow = (tid * SPT) >> 4, scol = (tid * SPT) & 15;
                 const double *Bsrc = Lb + (size_t)(c0 + srow) * ld + scol;
-                double bnext = Bsrc[0];
-                sm.Bs[0][srow][scol] = bnext;
-                v2d hn[2][2];
+                double bnext[SPT];
+#pragma unroll
+                for (int e = 0; e < SPT; e++) { bnext[e] = Bsrc[e]; sm.Bs[0][srow][scol + e] = bnext[e]; }
+                v2d hn[UPW][2];
                 if (active && cfirst < nch) {
 #pragma unroll
-                    for (int u = 0; u < 2; u++)
+                    for (int u = 0; u < UPW; u++)
 #pragma unroll
                         for (int h = 0; h < 2; h++)
                             hn[u][h] = *(const v2d *)(Hist + (size_t)(row0 + 16 * u + li) * ld + cfirst * CI_KC + 8 * h + 2 * g);
@@ -231,16 +249,19 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 __syncthreads();
                 for (int c = 0; c < nch; c++) {
                     const int buf = c & 1;
-                    if (c + 1 < nch) bnext = Bsrc[(c + 1) * CI_KC];
-                    if (active && c >= cfirst) {
-                        v2d hc[2][2];
+                    if (c + 1 < nch) {
 #pragma unroll
-                        for (int u = 0; u < 2; u++)
+                        for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[(c + 1) * CI_KC + e];
+                    }
+                    if (active && c >= cfirst) {
+                        v2d hc[UPW][2];
+#pragma unroll
+                        for (int u = 0; u < UPW; u++)
 #pragma unroll
                             for (int h = 0; h < 2; h++) hc[u][h] = hn[u][h];
                         if (c + 1 < nch) {
 #pragma unroll
-                            for (int u = 0; u < 2; u++)
+                            for (int u = 0; u < UPW; u++)
 #pragma unroll
                                 for (int h = 0; h < 2; h++)
                                     hn[u][h] = *(const v2d *)(Hist + (size_t)(row0 + 16 * u + li) * ld + (c + 1) * CI_KC + 8 * h + 2 * g);
@@ -253,32 +274,22 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                                 for (int s = 0; s < 2; s++)
 #pragma unroll
-                                    for (int u = 0; u < 2; u++)
+                                    for (int u = 0; u < UPW; u++)
                                         acc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], hc[u][h][s], acc[ct][u], 0, 0, 0);
                             }
                         }
                     }
                     // z history product (pass 0 only): wave 15, lane = panel column
-                    if (pass == 0 && wave == 15) {
+                    if (pass == 0 && wave == NW - 1) {
 #pragma unroll
                         for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * zz[c * CI_KC + kk];
                     }
-                    if (c + 1 < nch) sm.Bs[buf ^ 1][srow][scol] = bnext;
+                    if (c + 1 < nch) {
+#pragma unroll
+                        for (int e = 0; e < SPT; e++) sm.Bs[buf ^ 1][srow][scol + e] = bnext[e];
+                    }
                     __syncthreads();
                 }
-            }
-            // ---- acc <- init - acc   (init = K block for K rows, 0 for U rows)
-            if (active) {
-#pragma unroll
-                for (int ct = 0; ct < 4; ct++)
-#pragma unroll
-                    for (int u = 0; u < 2; u++)
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            double init = 0.0;
-                            if (isM) init = Lb[(size_t)(row0 + 16 * u + li) * ld + c0 + 16 * ct + 4 * r + g];
-                            acc[ct][u][r] = init - acc[ct][u][r];
-                        }
             }
             if (pass == 0) {
                 // diagonal block (block index 0 = waves 0,1) -> LDS, factor, invert
@@ -286,16 +297,13 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                     for (int ct = 0; ct < 4; ct++)
 #pragma unroll
-                        for (int u = 0; u < 2; u++)
+                        for (int u = 0; u < UPW; u++)
 #pragma unroll
-                            for (int r = 0; r < 4; r++) sm.Dk[32 * whalf + 16 * u + li][16 * ct + 4 * r + g] = acc[ct][u][r];
+                            for (int r = 0; r < 4; r++) sm.Dk[RPW * wsub + 16 * u + li][16 * ct + 4 * r + g] = -acc[ct][u][r];
                 }
-                if (wave == 15) sm.zacc[lane] = zsum;
+                if (wave == NW - 1) sm.zacc[lane] = zsum;
                 __syncthreads();
                 if (wave == 0) {
-                    if (want_inv & 2) {   // DEBUG timing experiment: skip the diagonal factorisation
-                        for (int c = 0; c < 64; c++) { sm.Xk[lane][c] = (lane == c) ? 1.0 : 0.0; }
-                    } else
                     diag_factor_wave(sm, lane);
                     if (!sm.fail) {
                         // z_k = L_kk^-1 (y_k - zacc)
@@ -309,30 +317,35 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 __syncthreads();
                 if (sm.fail) return false;
                 // store L_kk (lower) and U_kk = L_kk^-T (upper, zeros below)
-                for (int e = tid; e < 64 * 64; e += CI_THREADS) {
+                for (int e = tid; e < 64 * 64; e += NT) {
                     int rr = e >> 6, cc = e & 63;
                     if (cc <= rr) Lb[(size_t)(c0 + rr) * ld + c0 + cc] = sm.Dk[rr][cc];
                     if (want_inv) Ub[(size_t)(c0 + rr) * ld + c0 + cc] = (cc >= rr) ? sm.Xk[cc][rr] : 0.0;
                 }
             }
-            // ---- triangular solve as GEMM: out^T[ct] = sum_{ct' <= ct} Xk[ct, ct'] acc^T[ct'], then store
+            // ---- panel solve  L_kk out^T = val^T (val = -acc) by 16x16 tile substitution, in place in acc:
+            //        t = acc[ct] + sum_{cp<ct} L(ct,cp) out[cp];   out[ct] = (-X(ct,ct)) t
+            // The diagonal-block owner (pass 0, block 0) solves for the identity instead: its rows of the panel
+            // are U_kk = L_kk^-T, the diagonal block of the inverse factor.
+            // ---- triangular solve as GEMM: out^T[ct] = sum_{ct' <= ct} (-Xk[ct, ct']) acc^T[ct'], then store
+            //      (measured faster than substituting tile by tile: four independent accumulator chains per unit)
             if (active && !(pass == 0 && wblk == 0)) {
                 double *Out = isM ? Lb : Ub;
 #pragma unroll
                 for (int ct = 3; ct >= 0; ct--) {
-                    v4d o[2];
-                    o[0] = (v4d){0.0, 0.0, 0.0, 0.0};
-                    o[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+                    v4d o[UPW];
+#pragma unroll
+                    for (int u = 0; u < UPW; u++) o[u] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int cp = 0; cp <= ct; cp++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            double a = sm.Xk[16 * ct + li][16 * cp + 4 * r + g];
+                            double a = -sm.Xk[16 * ct + li][16 * cp + 4 * r + g];
 #pragma unroll
-                            for (int u = 0; u < 2; u++) o[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[cp][u][r], o[u], 0, 0, 0);
+                            for (int u = 0; u < UPW; u++) o[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[cp][u][r], o[u], 0, 0, 0);
                         }
 #pragma unroll
-                    for (int u = 0; u < 2; u++)
+                    for (int u = 0; u < UPW; u++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) Out[(size_t)(row0 + 16 * u + li) * ld + c0 + 16 * ct + 4 * r + g] = o[u][r];
                 }
@@ -343,15 +356,18 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
     return true;
 }
 
-// grid = nbatch, block = 1024
-__global__ void __launch_bounds__(CI_THREADS) k_cholinv(MedgpDev L, int want_inv) {
+// grid = nbatch, block = NW * 64.  NW = 16: one workgroup per CU (lowest latency per patient);
+// NW = 8: two workgroups per CU, the serial diagonal-block phase of one overlaps the MFMA phase of the other.
+template <int NW, int UPW>
+__global__ void __launch_bounds__(NW * 64, 2) k_cholinv(MedgpDev L, int want_inv) {
+    constexpr int NT = NW * 64;
     __shared__ CholInvSmem sm;
     const int b = blockIdx.x, tid = threadIdx.x;
     if (L.status[b] < 0) return;
     const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64);
     int count = 0;
     while (true) {
-        if (cholinv_attempt(L, b, slot, n, want_inv, sm)) break;
+        if (cholinv_attempt<NW, UPW>(L, b, slot, n, want_inv, sm)) break;
         __syncthreads();
         if (count >= 10) {   // ref: c_inference_exact.cpp:99,109-111
             if (tid == 0) L.status[b] = -1;
@@ -365,13 +381,13 @@ __global__ void __launch_bounds__(CI_THREADS) k_cholinv(MedgpDev L, int want_inv
     // quad = z^T z (fixed-order tree)
     {
         double s = 0.0;
-        for (int i = tid; i < npad; i += CI_THREADS) s += zz[i] * zz[i];
+        for (int i = tid; i < npad; i += NT) s += zz[i] * zz[i];
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
         if ((tid & 63) == 0) sm.red[tid >> 6] = s;
         __syncthreads();
         if (tid == 0) {
             double q = 0.0;
-            for (int w = 0; w < CI_THREADS / 64; w++) q += sm.red[w];
+            for (int w = 0; w < NW; w++) q += sm.red[w];
             L.status[b] = count;
             L.scal[b * 4 + 0] = sm.logdet;
             L.scal[b * 4 + 1] = q;
@@ -382,7 +398,7 @@ __global__ void __launch_bounds__(CI_THREADS) k_cholinv(MedgpDev L, int want_inv
         const double *Ub = L.Linv + (size_t)b * ld * ld;
         double *alpha = L.alpha + (size_t)b * ld;
         const int wave = tid >> 6, lane = tid & 63;
-        for (int r = wave; r < npad; r += CI_THREADS / 64) {
+        for (int r = wave; r < npad; r += NW) {
             double s = 0.0;
             for (int c = (r & ~63) + lane; c < npad; c += 64) s += Ub[(size_t)r * ld + c] * zz[c];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);

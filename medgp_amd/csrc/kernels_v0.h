@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) k_assemble_v0(MedgpDev L) {
 
 // whole-matrix re-assembly by one workgroup with `count` extra noise additions (jitter path)
 //   ref: c_inference_exact.cpp:99-108
-__device__ void reassemble_wg(const MedgpDev &L, int b, int slot, int n, int np, int count) {
+__device__ __attribute__((noinline)) void reassemble_wg(const MedgpDev &L, int b, int slot, int n, int np, int count) {
     const int ld = L.ldn;
     const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
     const double *cs = L.cs + (size_t)b * L.Q * ld, *sn = L.sn + (size_t)b * L.Q * ld;

@@ -19,6 +19,7 @@
 //            exactly once (no atomics).  k_epilogue adds the pieces in fixed order.
 #pragma once
 #include "medgp_dev.h"
+#include "kernels_assemble.h"
 
 #define WG_KC 32
 #define WG_THREADS 256
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
 #pragma unroll
         for (int q = 0; q < QT; q++) {
             const double ci = csb[q * ld + i], si = snb[q * ld + i];   // wave-uniform loads
-            const double E = exp(-cq[q] * dd);
+            const double E = exp_neg(cq[q] * dd);
             const double cd = ci * csj[q] + si * snj[q];
             const double sd = si * csj[q] - ci * snj[q];
             const double k = cd * E;

@@ -5,6 +5,7 @@
 #include "medgp_dev.h"
 #include "kernels_v0.h"
 #include "kernels_cholinv.h"
+#include "kernels_assemble.h"
 #include "kernels_wgrad.h"
 
 #include <algorithm>
@@ -57,6 +58,8 @@ struct medgp_ctx {
     // profiling
     bool profiling = false;
     bool use_v0 = false;      // MEDGP_V0=1: baseline kernels (debug / A-B parity)
+    int cholinv_nw = 0;       // MEDGP_CHOLINV_NW=8|16 forces the workgroup shape (0 = auto)
+    int num_cu = 256;
     std::vector<EvPair> events;
     double prof_ms[KID_COUNT] = {0};
     int64_t prof_n[KID_COUNT] = {0};
@@ -167,14 +170,33 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
     const MedgpDev &L = c->dev;
     const int nt64 = medgp_roundup(std::max(max_n, 1), 64) / 64;
     { Launcher l(c, KID_PREP); hipLaunchKernelGGL(k_prep, dim3(nbatch), dim3(256), 0, c->stream, L, theta_dev); }
-    { Launcher l(c, KID_ASSEMBLE); hipLaunchKernelGGL(k_assemble_v0, dim3(tri(nt64), nbatch), dim3(256), 0, c->stream, L); }
+    {
+        Launcher l(c, KID_ASSEMBLE);
+        const dim3 tg(tri(nt64), nbatch), tb(256);
+        switch (c->use_v0 ? 0 : L.Q) {
+        case 1: hipLaunchKernelGGL(k_assemble_t<1>, tg, tb, 0, c->stream, L); break;
+        case 2: hipLaunchKernelGGL(k_assemble_t<2>, tg, tb, 0, c->stream, L); break;
+        case 3: hipLaunchKernelGGL(k_assemble_t<3>, tg, tb, 0, c->stream, L); break;
+        case 4: hipLaunchKernelGGL(k_assemble_t<4>, tg, tb, 0, c->stream, L); break;
+        case 5: hipLaunchKernelGGL(k_assemble_t<5>, tg, tb, 0, c->stream, L); break;
+        case 6: hipLaunchKernelGGL(k_assemble_t<6>, tg, tb, 0, c->stream, L); break;
+        case 7: hipLaunchKernelGGL(k_assemble_t<7>, tg, tb, 0, c->stream, L); break;
+        case 8: hipLaunchKernelGGL(k_assemble_t<8>, tg, tb, 0, c->stream, L); break;
+        default: hipLaunchKernelGGL(k_assemble_v0, tg, tb, 0, c->stream, L); break;
+        }
+    }
     const bool inv = flag_grad || need_inverse;
     if (c->use_v0) {
         { Launcher l(c, KID_POTRF); hipLaunchKernelGGL(k_potrf_v0, dim3(nbatch), dim3(256), 0, c->stream, L); }
         if (inv) { Launcher l(c, KID_TRTRI); hipLaunchKernelGGL(k_trtri_v0, dim3(nbatch), dim3(256), 0, c->stream, L); }
     } else {
         Launcher l(c, KID_CHOLINV);
-        hipLaunchKernelGGL(k_cholinv, dim3(nbatch), dim3(CI_THREADS), 0, c->stream, L, (inv ? 1 : 0) | (getenv("MEDGP_DBG_SKIPDIAG") ? 2 : 0));
+        // more patients than CUs: 8-wave workgroups, two per CU (serial phases overlap); else 16 waves for latency
+        // more patients than CUs: 4-wave workgroups, two per CU (the serial diagonal phase of one overlaps the
+        // MFMA phase of the other); else 8 waves for the lowest latency per patient
+        const int shape = c->cholinv_nw ? c->cholinv_nw : (nbatch > c->num_cu ? 44 : 84);
+        if (shape == 44) hipLaunchKernelGGL((k_cholinv<4, 4>), dim3(nbatch), dim3(256), 0, c->stream, L, inv ? 1 : 0);
+        else hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, c->stream, L, inv ? 1 : 0);
     }
     int from_slab = 0;
     if (flag_grad) {
@@ -243,6 +265,8 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     }
     c->stream = c->own_stream;
     { const char *e = getenv("MEDGP_V0"); c->use_v0 = e && e[0] == '1'; }
+    { const char *e = getenv("MEDGP_CHOLINV_NW"); c->cholinv_nw = e ? atoi(e) : 0; }
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->num_cu = pr.multiProcessorCount; }
     *out = c;
     return MEDGP_OK;
 }
