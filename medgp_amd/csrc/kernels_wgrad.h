@@ -33,11 +33,14 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
     BsT Bs = (BsT)smem;                       // Bs[2][64][34]
     double (*Ws)[66] = (double (*)[66])smem;   // Ws[64][66]  (4224 <= 4352 doubles)
 
-    const int b = blockIdx.y;
+    // grid = (nbatch, tiles): the patient index is the fastest-varying block coordinate, so with workgroups
+    // dealt round-robin over the 8 XCDs all tiles of one patient land on one XCD and share its L2 (the
+    // U rows are re-read by every tile of the patient); heavy tiles (small I, long k range) are issued first.
+    const int b = blockIdx.x;
     if (L.status[b] < 0) return;
     const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
     int I, J;
-    tile_decode(blockIdx.x, I, J);
+    tile_decode(blockIdx.y, I, J);
     if (I >= nb) return;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -200,7 +200,7 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
     }
     int from_slab = 0;
     if (flag_grad) {
-        const dim3 tg(tri(nt64), nbatch), tb(WG_THREADS);
+        const dim3 tg(nbatch, tri(nt64)), tb(WG_THREADS);
         from_slab = 1;
         Launcher *lw = new Launcher(c, KID_WGRAD);
         switch (c->use_v0 ? 0 : L.Q) {
