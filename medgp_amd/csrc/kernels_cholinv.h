@@ -33,6 +33,7 @@ struct CholInvSmem {
     double Xk[64][66];             // L_kk^-1 (lower)
     double zacc[64];               // L[C_k, 0:64k] z[0:64k]
     double rhs[64];
+    double zk[64];                 // z of the current panel (for the in-step alpha accumulation)
     double rdiag[16];              // 1 / diag of the current 16x16 tile
     double red[16];
     double logdet;
@@ -192,8 +193,12 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
     double *Lb = L.Kmat + (size_t)b * ld * ld;
     double *Ub = L.Linv + (size_t)b * ld * ld;
     double *zz = L.z + (size_t)b * ld;
+    double *alpha = L.alpha + (size_t)b * ld;
     const double *y = L.py + (size_t)slot * ld;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // virtual wave id: odd batch entries mirror the wave order, so that when two workgroups share a CU the
+    // heavy waves (diagonal owner, longest histories) of one sit beside the light waves of the other
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (b & 1) ? (NW - 1 - (tid >> 6)) : (tid >> 6);
     const int li = lane & 15, g = lane >> 4;
     const int wblk = wave / WPB, wsub = wave % WPB;
 
@@ -207,7 +212,8 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
         const int npass = (ntot + BP - 1) / BP;
         const int nch = c0 / CI_KC;                  // history chunks
         for (int pass = 0; pass < npass; pass++) {
-            const int bidx = pass * BP + wblk;
+            // odd passes walk the block list backwards: pairs long histories with short ones per wave
+            const int bidx = pass * BP + ((pass & 1) ? (BP - 1 - wblk) : wblk);
             const bool active = bidx < ntot;
             const bool isM = bidx < nM;
             const int rblk = isM ? (k + bidx) : (bidx - nM);           // row block of this wave
@@ -312,6 +318,14 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                         double s = 0.0;
                         for (int cc = 0; cc <= lane; cc++) s += sm.Xk[lane][cc] * sm.rhs[cc];
                         zz[c0 + lane] = s;
+                        sm.zk[lane] = s;
+                        if (want_inv) {
+                            // alpha = U z accumulated panel by panel; the diagonal block U_kk = L_kk^-T opens rows C_k
+                            __builtin_amdgcn_wave_barrier();
+                            double a0 = 0.0;
+                            for (int cc = lane; cc < 64; cc++) a0 += sm.Xk[cc][lane] * sm.zk[cc];
+                            alpha[c0 + lane] = a0;
+                        }
                     }
                 }
                 __syncthreads();
@@ -331,6 +345,9 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
             //      (measured faster than substituting tile by tile: four independent accumulator chains per unit)
             if (active && !(pass == 0 && wblk == 0)) {
                 double *Out = isM ? Lb : Ub;
+                double pal[UPW];
+#pragma unroll
+                for (int u = 0; u < UPW; u++) pal[u] = 0.0;
 #pragma unroll
                 for (int ct = 3; ct >= 0; ct--) {
                     v4d o[UPW];
@@ -348,6 +365,23 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     for (int u = 0; u < UPW; u++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) Out[(size_t)(row0 + 16 * u + li) * ld + c0 + 16 * ct + 4 * r + g] = o[u][r];
+                    if (!isM) {   // U rows: alpha_i += sum_c U[i][c] z_k[c]
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const double zc = sm.zk[16 * ct + 4 * r + g];
+#pragma unroll
+                            for (int u = 0; u < UPW; u++) pal[u] += o[u][r] * zc;
+                        }
+                    }
+                }
+                if (!isM) {
+#pragma unroll
+                    for (int u = 0; u < UPW; u++) {
+                        double v = pal[u];
+                        v += __shfl_xor(v, 16);
+                        v += __shfl_xor(v, 32);
+                        if (g == 0) alpha[row0 + 16 * u + li] += v;   // this wave owns these rows in this step
+                    }
                 }
             }
             __syncthreads();   // stores of this step visible to the whole workgroup before the next history read
@@ -393,16 +427,5 @@ __global__ void __launch_bounds__(NW * 64, 2) k_cholinv(MedgpDev L, int want_inv
             L.scal[b * 4 + 1] = q;
         }
     }
-    // alpha = L^-T z = U z : one wave per row, fixed-order shuffle tree
-    if (want_inv) {
-        const double *Ub = L.Linv + (size_t)b * ld * ld;
-        double *alpha = L.alpha + (size_t)b * ld;
-        const int wave = tid >> 6, lane = tid & 63;
-        for (int r = wave; r < npad; r += NW) {
-            double s = 0.0;
-            for (int c = (r & ~63) + lane; c < npad; c += 64) s += Ub[(size_t)r * ld + c] * zz[c];
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-            if (lane == 0) alpha[r] = s;
-        }
-    }
+    // alpha = L^-T z was accumulated panel by panel inside cholinv_attempt
 }
