@@ -1,0 +1,199 @@
+// host_logic_test.cpp -- CPU-only checks of the host logic (no GPU, no libmedgp_hip):
+//   scg            : the resumable scg_machine against a direct loop-structured statement of the same algorithm
+//                    (ref: util/c_optimizer_scg.cpp:25-284) on analytic objectives; evaluation budget semantics
+//   hyp  cfg out   : dump c_experiment::get_global_hyp (srand/rand draws) as doubles
+//   data cfg PAN out: dump one patient's (meta, t, y) as loaded + z-scored
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <iostream>
+#include <vector>
+
+#include "medgp_experiment.hpp"
+#include "medgp_optimizer.hpp"
+using namespace medgp;
+typedef std::vector<double> vec;
+typedef std::function<bool(const vec &, double &, vec &)> objective_t;
+
+static double dotp(const vec &a, const vec &b) { double s = 0; for (size_t i = 0; i < a.size(); i++) s += a[i] * b[i]; return s; }
+
+// direct statement with the reference's loop structure (for cross-checking the state machine)
+static void scg_direct(int max_iteration, const vec &init, const objective_t &obj, double &opt_loss, vec &X, int &nev) {
+    const double INT = 0.1, EXT = 3.0, MAX = 20, RATIO = 10, SIG = 0.1, RHO = SIG / 2.0;
+    const int sb = std::signbit((double)max_iteration) ? 1 : 0;
+    int i = 0; nev = 0;
+    double f0, d0, x1 = 0, x2 = 0, x3, x4 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, F0, M;
+    vec df0, df3, dF0, X0, s;
+    bool flag = obj(init, f0, df0); nev++;
+    i += sb;
+    s.resize(df0.size());
+    for (size_t j = 0; j < s.size(); j++) s[j] = -df0[j];
+    d0 = -dotp(s, s);
+    x3 = 1.0 / (1.0 - d0);
+    opt_loss = f0; X = init;
+    while (i < std::abs(max_iteration)) {
+        i += sb + (max_iteration > 0 ? 1 : 0);
+        X0 = X; F0 = opt_loss; dF0 = df0;
+        M = (max_iteration > 0) ? MAX : std::min((int)MAX, std::abs(max_iteration) - i);
+        while (1) {
+            x2 = 0; f2 = opt_loss; d2 = d0; f3 = opt_loss; df3 = df0;
+            bool success = false;
+            while (!success && M > 0) {
+                M -= 1; i += sb;
+                vec np(X.size());
+                for (size_t j = 0; j < X.size(); j++) np[j] = X[j] + x3 * s[j];
+                double ft; vec gt;
+                flag = obj(np, ft, gt); nev++;
+                if (flag) { f3 = ft; df3 = gt; }
+                if (!flag || std::isinf(f3) || std::isnan(f3)) x3 = (x2 + x3) / 2.0; else success = true;
+            }
+            if (f3 < F0) { for (size_t j = 0; j < X.size(); j++) X0[j] = X[j] + x3 * s[j]; F0 = f3; dF0 = df3; }
+            d3 = dotp(df3, s);
+            if (d3 > SIG * d0 || f3 > opt_loss + x3 * RHO * d0 || M == 0) break;
+            x1 = x2; f1 = f2; d1 = d2; x2 = x3; f2 = f3; d2 = d3;
+            double A = 6.0 * (f1 - f2) + 3.0 * (d2 + d1) * (x2 - x1), B = 3.0 * (f2 - f1) - (2.0 * d1 + d2) * (x2 - x1);
+            double temp = B * B - A * d1 * (x2 - x1);
+            if (temp < 0) x3 = x2 * EXT;
+            else {
+                x3 = x1 - (d1 * std::pow(x2 - x1, 2.0) / (B + std::sqrt(temp)));
+                if (std::isnan(x3) || std::isinf(x3) || x3 < 0) x3 = x2 * EXT;
+                else if (x3 > x2 * EXT) x3 = x2 * EXT;
+                else if (x3 < x2 + INT * (x2 - x1)) x3 = x2 + INT * (x2 - x1);
+            }
+        }
+        while ((std::fabs(d3) > -SIG * d0 || f3 > opt_loss + x3 * RHO * d0) && M > 0) {
+            if (d3 > 0 || f3 > opt_loss + x3 * RHO * d0) { x4 = x3; f4 = f3; d4 = d3; } else { x2 = x3; f2 = f3; d2 = d3; }
+            if (f4 > opt_loss) {
+                x3 = x2 - (0.5 * d2 * std::pow(x4 - x2, 2.0)) / (f4 - f2 - d2 * (x4 - x2));
+                if (std::isnan(x3) || std::isinf(x3)) x3 = (x2 + x4) / 2.0;
+            } else {
+                double A = 6.0 * (f2 - f4) / (x4 - x2) + 3.0 * (d4 + d2), B = 3.0 * (f4 - f2) - (2.0 * d2 + d4) * (x4 - x2);
+                double disc = B * B - A * d2 * std::pow(x4 - x2, 2.0);
+                if (disc < 0) x3 = (x2 + x4) / 2.0;
+                else { x3 = x2 + (std::sqrt(disc) - B) / A; if (std::isnan(x3) || std::isinf(x3)) x3 = (x2 + x4) / 2.0; }
+            }
+            x3 = std::max(std::min(x3, x4 - INT * (x4 - x2)), x2 + INT * (x4 - x2));
+            vec np(X.size());
+            for (size_t j = 0; j < X.size(); j++) np[j] = X[j] + x3 * s[j];
+            double ft; vec gt;
+            flag = obj(np, ft, gt); nev++;
+            if (flag) { f3 = ft; df3 = gt; }
+            if (flag && f3 < F0) { for (size_t j = 0; j < X.size(); j++) X0[j] = X[j] + x3 * s[j]; F0 = f3; dF0 = df3; }
+            M -= 1; i += sb;
+            d3 = dotp(df3, s);
+        }
+        if (flag && std::fabs(d3) < -SIG * d0 && f3 < opt_loss + x3 * RHO * d0) {
+            for (size_t j = 0; j < X.size(); j++) X[j] += x3 * s[j];
+            opt_loss = f3;
+            double a = dotp(df3, df3), b = dotp(df3, df0), c = dotp(df0, df0);
+            for (size_t j = 0; j < s.size(); j++) s[j] = ((a - b) / c) * s[j] - df3[j];
+            df0 = df3; d3 = d0; d0 = dotp(df0, s);
+            if (d0 > 0) { for (size_t j = 0; j < s.size(); j++) s[j] = -df0[j]; d0 = -dotp(s, s); }
+            x3 = x3 * std::min(RATIO, d3 / (d0 - std::pow(2.0, -52)));
+        } else {
+            X = X0; opt_loss = F0; df0 = dF0;
+            for (size_t j = 0; j < s.size(); j++) s[j] = -df0[j];
+            d0 = -dotp(s, s);
+            x3 = 1.0 / (1.0 - d0);
+        }
+    }
+}
+
+static bool rosen(const vec &x, double &f, vec &g) {
+    f = 0; g.assign(x.size(), 0.0);
+    for (size_t i = 0; i + 1 < x.size(); i++) {
+        double a = x[i + 1] - x[i] * x[i], b = 1 - x[i];
+        f += 100 * a * a + b * b;
+        g[i] += -400 * a * x[i] - 2 * b;
+        g[i + 1] += 200 * a;
+    }
+    return true;
+}
+static bool quad(const vec &x, double &f, vec &g) {
+    f = 0; g.assign(x.size(), 0.0);
+    for (size_t i = 0; i < x.size(); i++) { double w = 1.0 + 3.0 * i; f += 0.5 * w * (x[i] - 0.3 * i) * (x[i] - 0.3 * i); g[i] = w * (x[i] - 0.3 * i); }
+    return true;
+}
+// objective with a failure region and a NaN region (exercises the bisection branch, ref :125-131)
+static bool hole(const vec &x, double &f, vec &g) {
+    if (x[0] > 2.5) return false;
+    bool ok = quad(x, f, g);
+    if (x[1] > 4.0) f = NAN;
+    return ok;
+}
+
+static int run_machine(int budget, const vec &init, const objective_t &obj, double &loss, vec &X) {
+    scg_machine m;
+    m.start(budget, init);
+    int n = 0;
+    while (!m.done()) {
+        vec th = m.request(), g;
+        double f = 0;
+        bool ok = obj(th, f, g);
+        n++;
+        m.feed(ok, f, g);
+    }
+    loss = m.opt_loss; X = m.opt_parameter;
+    return n;
+}
+
+static int test_scg() {
+    int bad = 0;
+    struct Case { const char *name; objective_t obj; vec init; int budget; };
+    std::vector<Case> cases = {
+        {"quad/-100", quad, vec(6, 2.0), -100}, {"quad/-7", quad, vec(6, 2.0), -7}, {"quad/+5", quad, vec(6, 2.0), 5},
+        {"quad/-1", quad, vec(6, 2.0), -1}, {"quad/-2", quad, vec(6, 2.0), -2},
+        {"rosen/-100", rosen, {-1.2, 1.0, -0.5, 0.8}, -100}, {"rosen/-1000", rosen, {-1.2, 1.0, -0.5, 0.8}, -1000},
+        {"rosen/-30", rosen, {-1.2, 1.0, -0.5, 0.8}, -30}, {"hole/-60", hole, {2.4, 3.9, 0.0}, -60},
+    };
+    for (auto &c : cases) {
+        double l1, l2, f0; vec X1, X2, g0;
+        int n2 = 0;
+        int n1 = run_machine(c.budget, c.init, c.obj, l1, X1);
+        scg_direct(c.budget, c.init, c.obj, l2, X2, n2);
+        c.obj(c.init, f0, g0);
+        bool same = (n1 == n2) && (l1 == l2) && (X1 == X2);
+        bool budget_ok = c.budget > 0 || n1 <= -c.budget;
+        bool descent = !(l1 > f0);
+        printf("%-12s evals %4d/%4d loss %.12g (start %.6g)  same=%d budget=%d descent=%d\n", c.name, n1, n2, l1, f0, same, budget_ok, descent);
+        if (!same || !budget_ok || !descent) bad++;
+    }
+    // convergence
+    double l; vec X;
+    run_machine(-1000, {-1.2, 1.0, -0.5, 0.8}, rosen, l, X);
+    if (!(l < 1e-10)) { printf("rosenbrock did not converge: %g\n", l); bad++; }
+    run_machine(-100, vec(6, 2.0), quad, l, X);
+    if (!(l < 1e-12)) { printf("quadratic did not converge: %g\n", l); bad++; }
+    printf(bad ? "SCG_FAIL\n" : "SCG_PASS\n");
+    return bad;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 2 && !strcmp(argv[1], "scg")) return test_scg();
+    if (argc >= 4 && !strcmp(argv[1], "hyp")) {
+        c_experiment e;
+        if (!e.load(argv[2])) { printf("ERROR: %s\n", e.error().c_str()); return 1; }
+        std::vector<vec> g;
+        e.get_global_hyp(g);
+        FILE *f = fopen(argv[3], "wb");
+        for (auto &h : g) fwrite(h.data(), 8, h.size(), f);
+        fclose(f);
+        printf("HYP %d %d lik %d cov %d\n", (int)g.size(), e.get_hyp_num(), e.get_lik_num(), e.get_cov_num());
+        return 0;
+    }
+    if (argc >= 5 && !strcmp(argv[1], "data")) {
+        c_experiment e;
+        if (!e.load(argv[2])) { printf("ERROR: %s\n", e.error().c_str()); return 1; }
+        std::vector<int> m; std::vector<float> t, y;
+        if (!e.get_one_patient_data(argv[3], m, t, y)) { printf("ERROR: %s\n", e.error().c_str()); return 1; }
+        FILE *f = fopen(argv[4], "wb");
+        int n = (int)t.size();
+        fwrite(&n, 4, 1, f); fwrite(m.data(), 4, n, f); fwrite(t.data(), 4, n, f); fwrite(y.data(), 4, n, f);
+        fclose(f);
+        printf("DATA %d\n", n);
+        return 0;
+    }
+    printf("usage: host_logic_test scg | hyp cfg out | data cfg PAN out\n");
+    return 2;
+}
