@@ -120,6 +120,13 @@ int medgp_get_factor(medgp_ctx *ctx, int b, float *alpha, float *linv, float *be
 int medgp_fit_predict(medgp_ctx *ctx, int slot, const double *theta, int nstar, const int32_t *meta2,
                       const float *t2, float *mean, float *var, int32_t *status);
 
+/* nbatch independent (train(false) + predict ONE point) problems in one call: problem b uses patient
+ * slots[b], hypers theta[b*H..), test point (meta2[b], t2[b]).  This is the inner body of the online
+ * imputation loop, ref: main_one_test.cpp:352-409 (N* = 1 there, :369-372), batched over the (time stamp,
+ * observation) pairs of a patient, each uploaded as its own slot (a subset of the patient's observations). */
+int medgp_fit_predict_batch(medgp_ctx *ctx, int nbatch, const int32_t *slots, const double *theta,
+                            const int32_t *meta2, const float *t2, float *mean, float *var, int32_t *status);
+
 /* block until all work queued on the context's stream is complete */
 int medgp_synchronize(medgp_ctx *ctx);
 

@@ -20,7 +20,7 @@ SYMBOLS = [
     "medgp_abi_version", "medgp_device_count", "medgp_create", "medgp_destroy", "medgp_last_error",
     "medgp_num_hyp", "medgp_set_pi", "medgp_set_stream", "medgp_reserve", "medgp_set_patient",
     "medgp_set_prior", "medgp_nlml_grad", "medgp_nlml_grad_device", "medgp_get_factor",
-    "medgp_fit_predict", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
+    "medgp_fit_predict", "medgp_fit_predict_batch", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
     "medgp_profile_kernel_name", "medgp_profile_read", "medgp_profile_reset",
 ]
 
@@ -72,6 +72,7 @@ def load():
     lib.medgp_nlml_grad_device.argtypes = [vp, C.c_int, i32p, vp, C.c_int, vp, vp, vp]
     lib.medgp_get_factor.argtypes = [vp, C.c_int, fp, fp, fp]
     lib.medgp_fit_predict.argtypes = [vp, C.c_int, dp, C.c_int, i32p, fp, fp, fp, i32p]
+    lib.medgp_fit_predict_batch.argtypes = [vp, C.c_int, i32p, dp, i32p, fp, fp, fp, i32p]
     lib.medgp_synchronize.argtypes = [vp]
     lib.medgp_profile_enable.argtypes = [vp, C.c_int]
     lib.medgp_profile_num_kernels.restype = C.c_int
@@ -182,6 +183,21 @@ class Context:
         self._chk(self._lib.medgp_fit_predict(self._h, int(slot), _ptr(theta, C.c_double), ns, _ptr(meta2, C.c_int32),
                                               _ptr(t2, C.c_float), _ptr(mean, C.c_float), _ptr(var, C.c_float), C.byref(st)))
         return mean, var, st.value
+
+    def fit_predict_batch(self, slots, theta, meta2, t2):
+        """One test point per problem: problem b = (slots[b], theta[b], meta2[b], t2[b])."""
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        nb = slots.shape[0]
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(nb, self.H)
+        t2 = np.ascontiguousarray(t2, dtype=np.float32)
+        meta2 = None if meta2 is None else np.ascontiguousarray(meta2, dtype=np.int32)
+        mean = np.empty(nb, dtype=np.float32)
+        var = np.empty(nb, dtype=np.float32)
+        st = np.empty(nb, dtype=np.int32)
+        self._chk(self._lib.medgp_fit_predict_batch(self._h, nb, _ptr(slots, C.c_int32), _ptr(theta, C.c_double),
+                                                    _ptr(meta2, C.c_int32), _ptr(t2, C.c_float), _ptr(mean, C.c_float),
+                                                    _ptr(var, C.c_float), _ptr(st, C.c_int32)))
+        return mean, var, st
 
     def synchronize(self):
         self._chk(self._lib.medgp_synchronize(self._h))

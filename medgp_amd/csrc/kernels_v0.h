@@ -11,7 +11,7 @@
 // The tables implement cos(w (t_i - t_j)) = cs_i cs_j + sn_i sn_j, so the N^2 pair loop needs no
 // trigonometric evaluation (c_kernel_LMC_SM.cpp:374-378 evaluates cos per pair).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restrict__ theta) {
+__global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restrict__ theta, int min_n) {
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int slot = L.bslot[b];
     const int n = L.pn[slot];
@@ -21,7 +21,9 @@ __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restri
     const int Q = L.Q, D = L.D, R = L.R;
     const double pi = L.pi;
     if (tid == 0) {
-        L.status[b] = (n > 2) ? 0 : -1;   // ref: util/c_objective_one.cpp:51
+        // objective path: n > 2 (ref util/c_objective_one.cpp:51); train(false)+predict path: any n >= 1
+        // (GP_Regression::train has no such guard, ref core/gp_regression.cpp:102-126)
+        L.status[b] = (n >= min_n) ? 0 : -1;
         L.scal[b * 4 + 0] = 0.0;
         L.scal[b * 4 + 1] = 0.0;
     }
@@ -598,11 +600,12 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
 // predict: one workgroup per test point.  mean = k*^T alpha; var = k** - |L^-1 k*|^2 + sigma^2
 //   ref: core/gp_regression.cpp:128-214, c_kernel_LMC_SM.cpp:329-372, :122-150
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_predict_v0(MedgpDev L, int b, int nstar, const int *__restrict__ meta2,
+// grid = (nstar, nbatch): test point js of problem b lives at index b * nstar + js of meta2 / t2 / mean / var
+__global__ void __launch_bounds__(256) k_predict_v0(MedgpDev L, int nstar, const int *__restrict__ meta2,
                                                    const double *__restrict__ t2, double *__restrict__ ks_buf,
                                                    float *__restrict__ mean, float *__restrict__ var) {
     __shared__ double red[256];
-    const int js = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int b = blockIdx.y, js = b * nstar + blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, Q = L.Q, D = L.D;
     if (L.status[b] < 0) {
         if (tid == 0) { mean[js] = __builtin_nanf(""); var[js] = __builtin_nanf(""); }

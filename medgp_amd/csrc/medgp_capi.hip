@@ -165,11 +165,11 @@ int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out) {
 inline int tri(int n) { return n * (n + 1) / 2; }
 
 // the evaluation pipeline; everything is asynchronous on c->stream
-int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, int flag_grad, bool need_inverse,
+int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, int flag_grad, bool need_inverse, int min_n,
                  double *nlml_dev, double *grad_dev, int32_t *status_dev) {
     const MedgpDev &L = c->dev;
     const int nt64 = medgp_roundup(std::max(max_n, 1), 64) / 64;
-    { Launcher l(c, KID_PREP); hipLaunchKernelGGL(k_prep, dim3(nbatch), dim3(256), 0, c->stream, L, theta_dev); }
+    { Launcher l(c, KID_PREP); hipLaunchKernelGGL(k_prep, dim3(nbatch), dim3(256), 0, c->stream, L, theta_dev, min_n); }
     {
         Launcher l(c, KID_ASSEMBLE);
         const dim3 tg(tri(nt64), nbatch), tb(256);
@@ -460,7 +460,7 @@ int medgp_nlml_grad_device(medgp_ctx *c, int nbatch, const int32_t *slots, const
     HIPCHK(c, hipSetDevice(c->device));
     int max_n = 0, rc;
     if ((rc = set_batch(c, nbatch, slots, &max_n))) return rc;
-    return run_pipeline(c, nbatch, max_n, theta_dev, flag_grad, false, nlml_dev, grad_dev, status_dev);
+    return run_pipeline(c, nbatch, max_n, theta_dev, flag_grad, false, 3, nlml_dev, grad_dev, status_dev);
 }
 
 int medgp_nlml_grad(medgp_ctx *c, int nbatch, const int32_t *slots, const double *theta, int flag_grad, double *nlml,
@@ -514,15 +514,17 @@ int medgp_get_factor(medgp_ctx *c, int b, float *alpha, float *linv, float *beta
     return MEDGP_OK;
 }
 
-int medgp_fit_predict(medgp_ctx *c, int slot, const double *theta, int nstar, const int32_t *meta2, const float *t2,
-                      float *mean, float *var, int32_t *status) {
+// common part of medgp_fit_predict / medgp_fit_predict_batch: nbatch problems x nstar test points each
+static int fit_predict_impl(medgp_ctx *c, int nbatch, const int32_t *slots, const double *theta, int nstar,
+                            const int32_t *meta2, const float *t2, float *mean, float *var, int32_t *status) {
     if (!c) return MEDGP_ERR_ARG;
-    if (!theta || !t2 || !mean || !var || nstar < 1) return fail(c, MEDGP_ERR_ARG, "bad argument");
+    if (!slots || !theta || !t2 || !mean || !var || nstar < 1 || nbatch < 1) return fail(c, MEDGP_ERR_ARG, "bad argument");
     if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
     if (c->kidx == MEDGP_KERNEL_LMC_SM && !meta2) return fail(c, MEDGP_ERR_ARG, "meta2 is NULL for the multi-output kernel");
     HIPCHK(c, hipSetDevice(c->device));
-    if (nstar > c->pred_cap) {
-        int cap = std::max(nstar, 64), rc;
+    const int ntot = nbatch * nstar;
+    if (ntot > c->pred_cap) {
+        int cap = std::max(ntot, 64), rc;
         if ((rc = dalloc(c, &c->d_t2, cap))) return rc;
         if ((rc = dalloc(c, &c->d_meta2, cap))) return rc;
         if ((rc = dalloc(c, &c->d_mean, cap))) return rc;
@@ -530,34 +532,43 @@ int medgp_fit_predict(medgp_ctx *c, int slot, const double *theta, int nstar, co
         if ((rc = dalloc(c, &c->d_ks, (size_t)cap * c->ldn))) return rc;
         c->pred_cap = cap;
     }
-    int32_t s1 = slot;
     int max_n = 0, rc;
-    if ((rc = set_batch(c, 1, &s1, &max_n))) return rc;
-    std::vector<double> ht2(nstar);
-    std::vector<int> hm2(nstar, 0);
-    for (int j = 0; j < nstar; j++) {
+    if ((rc = set_batch(c, nbatch, slots, &max_n))) return rc;
+    std::vector<double> ht2(ntot);
+    std::vector<int> hm2(ntot, 0);
+    for (int j = 0; j < ntot; j++) {
         ht2[j] = (double)t2[j];
         if (meta2 && c->kidx == MEDGP_KERNEL_LMC_SM) {
             if (meta2[j] < 0 || meta2[j] >= c->D) return fail(c, MEDGP_ERR_ARG, "meta2[%d] = %d outside [0, %d)", j, meta2[j], c->D);
             hm2[j] = meta2[j];
         }
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * c->H, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_t2, ht2.data(), sizeof(double) * nstar, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_meta2, hm2.data(), sizeof(int) * nstar, hipMemcpyHostToDevice, c->stream));
-    if ((rc = run_pipeline(c, 1, max_n, c->d_theta, 0, true, nullptr, nullptr, nullptr))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * c->H * nbatch, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_t2, ht2.data(), sizeof(double) * ntot, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_meta2, hm2.data(), sizeof(int) * ntot, hipMemcpyHostToDevice, c->stream));
+    if ((rc = run_pipeline(c, nbatch, max_n, c->d_theta, 0, true, 1, nullptr, nullptr, nullptr))) return rc;
     {
         Launcher l(c, KID_PREDICT);
-        hipLaunchKernelGGL(k_predict_v0, dim3(nstar), dim3(256), 0, c->stream, c->dev, 0, nstar, c->d_meta2, c->d_t2, c->d_ks, c->d_mean, c->d_var);
+        hipLaunchKernelGGL(k_predict_v0, dim3(nstar, nbatch), dim3(256), 0, c->stream, c->dev, nstar, c->d_meta2, c->d_t2, c->d_ks, c->d_mean, c->d_var);
     }
     HIPCHK(c, hipGetLastError());
-    int st = 0;
-    HIPCHK(c, hipMemcpyAsync(mean, c->d_mean, sizeof(float) * nstar, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(var, c->d_var, sizeof(float) * nstar, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(mean, c->d_mean, sizeof(float) * ntot, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(var, c->d_var, sizeof(float) * ntot, hipMemcpyDeviceToHost, c->stream));
+    if (status) HIPCHK(c, hipMemcpyAsync(status, c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (status) *status = st;
     return MEDGP_OK;
+}
+
+int medgp_fit_predict(medgp_ctx *c, int slot, const double *theta, int nstar, const int32_t *meta2, const float *t2,
+                      float *mean, float *var, int32_t *status) {
+    int32_t s1 = slot;
+    return fit_predict_impl(c, 1, &s1, theta, nstar, meta2, t2, mean, var, status);
+}
+
+int medgp_fit_predict_batch(medgp_ctx *c, int nbatch, const int32_t *slots, const double *theta, const int32_t *meta2,
+                            const float *t2, float *mean, float *var, int32_t *status) {
+    if (c && nbatch > c->max_batch) return fail(c, MEDGP_ERR_CAPACITY, "nbatch %d outside [1, %d]", nbatch, c->max_batch);
+    return fit_predict_impl(c, nbatch, slots, theta, 1, meta2, t2, mean, var, status);
 }
 
 int medgp_profile_enable(medgp_ctx *c, int enable) {
