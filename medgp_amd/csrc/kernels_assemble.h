@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_assemble_t(MedgpDev L) {
                 const double cd = csb[q * ld + i] * csj[q] + snb[q * ld + i] * snj[q];
                 acc += Brow[q * D * D] * (cd * exp_neg(cq[q] * dd));
             }
-            if (i == j) acc += hyp[mj];
+            if (i == j) { const double lik = hyp[mj]; acc += lik; for (int r = 0; r < L.jit[b]; r++) acc += lik; }   // ref c_inference_exact.cpp:88-92, :101-104
             v = jv ? acc : 0.0;
         } else v = (i == j) ? 1.0 : 0.0;
         K[(size_t)i * ld + j] = v;

@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restri
         L.status[b] = (n >= min_n) ? 0 : -1;
         L.scal[b * 4 + 0] = 0.0;
         L.scal[b * 4 + 1] = 0.0;
+        L.jit[b] = 0;
     }
     if (L.kidx == 7) {
         for (int d = tid; d < D; d += nt) { double s = exp(th[d]); sig2[d] = s * s; }
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(256) k_assemble_v0(MedgpDev L) {
             double v;
             if (i < n && j < n) {
                 v = cov_elem(L, hyp, cs, sn, t, meta, i, j);
-                if (i == j) v += hyp[meta[i]];
+                if (i == j) { const double lik = hyp[meta[i]]; v += lik; for (int r = 0; r < L.jit[b]; r++) v += lik; }
             } else v = (i == j) ? 1.0 : 0.0;
             K[(size_t)i * ld + j] = v;
         }

@@ -5,6 +5,7 @@
 #include "medgp_dev.h"
 #include "kernels_v0.h"
 #include "kernels_cholinv.h"
+#include "kernels_cholinv_mc.h"
 #include "kernels_assemble.h"
 #include "kernels_wgrad.h"
 
@@ -19,8 +20,8 @@
 
 namespace {
 
-enum KernelId { KID_PREP = 0, KID_ASSEMBLE, KID_POTRF, KID_TRTRI, KID_CHOLINV, KID_LAUUM, KID_GRADBINS, KID_WGRAD, KID_EPILOGUE, KID_PREDICT, KID_COUNT };
-const char *const kKernelNames[KID_COUNT] = {"k_prep", "k_assemble", "k_potrf", "k_trtri", "k_cholinv", "k_lauum", "k_gradbins", "k_wgrad", "k_epilogue", "k_predict"};
+enum KernelId { KID_PREP = 0, KID_ASSEMBLE, KID_POTRF, KID_TRTRI, KID_CHOLINV, KID_CI_PANEL, KID_CI_TRSM, KID_LAUUM, KID_GRADBINS, KID_WGRAD, KID_EPILOGUE, KID_PREDICT, KID_COUNT };
+const char *const kKernelNames[KID_COUNT] = {"k_prep", "k_assemble", "k_potrf", "k_trtri", "k_cholinv", "k_ci_panel", "k_ci_trsm", "k_lauum", "k_gradbins", "k_wgrad", "k_epilogue", "k_predict"};
 
 std::string g_create_error;
 
@@ -37,7 +38,7 @@ struct medgp_ctx {
     MedgpDev dev{};
     // device allocations
     std::vector<void *> allocs;
-    int *d_proff = nullptr, *d_pcoff = nullptr;
+    int *d_proff = nullptr, *d_pcoff = nullptr, *d_jit = nullptr;
     int *d_pn = nullptr, *d_pmeta = nullptr, *d_pseg = nullptr, *d_bslot = nullptr, *d_status = nullptr;
     double *d_pt = nullptr, *d_py = nullptr;
     MedgpPrior *d_prior = nullptr;
@@ -58,7 +59,8 @@ struct medgp_ctx {
     // profiling
     bool profiling = false;
     bool use_v0 = false;      // MEDGP_V0=1: baseline kernels (debug / A-B parity)
-    int cholinv_nw = 0;       // MEDGP_CHOLINV_NW=8|16 forces the workgroup shape (0 = auto)
+    int cholinv_nw = 0;       // MEDGP_CHOLINV_NW=44|84 forces the workgroup shape (0 = auto)
+    int force_mc = 0;         // MEDGP_MULTI_CU=1 forces / -1 forbids the multi-CU factorisation (0 = auto)
     int num_cu = 256;
     std::vector<EvPair> events;
     double prof_ms[KID_COUNT] = {0};
@@ -170,7 +172,7 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
     const MedgpDev &L = c->dev;
     const int nt64 = medgp_roundup(std::max(max_n, 1), 64) / 64;
     { Launcher l(c, KID_PREP); hipLaunchKernelGGL(k_prep, dim3(nbatch), dim3(256), 0, c->stream, L, theta_dev, min_n); }
-    {
+    auto launch_assemble = [&]() {
         Launcher l(c, KID_ASSEMBLE);
         const dim3 tg(tri(nt64), nbatch), tb(256);
         switch (c->use_v0 ? 0 : L.Q) {
@@ -184,14 +186,58 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
         case 8: hipLaunchKernelGGL(k_assemble_t<8>, tg, tb, 0, c->stream, L); break;
         default: hipLaunchKernelGGL(k_assemble_v0, tg, tb, 0, c->stream, L); break;
         }
-    }
+    };
     const bool inv = flag_grad || need_inverse;
+    // few large patients: one workgroup per 64-row block and two launches per panel (kernels_cholinv_mc.h)
+    // measured on MI355X (D=24): N=512: 64 patients 0.77 vs 1.15 ms, 256 patients 2.7 vs 1.35 ms; N=1024 x 64: 3.7 vs 6.2 ms;
+    // N=2048 x 16: 5.6 vs 38 ms  (multi-CU vs one workgroup per patient)
+    const bool multi_cu = !c->use_v0 && (c->force_mc > 0 || (c->force_mc == 0 && nt64 >= 2 && (nbatch <= c->num_cu / 2 || (nbatch < c->num_cu && nt64 >= 16))));
     if (c->use_v0) {
+        launch_assemble();
         { Launcher l(c, KID_POTRF); hipLaunchKernelGGL(k_potrf_v0, dim3(nbatch), dim3(256), 0, c->stream, L); }
         if (inv) { Launcher l(c, KID_TRTRI); hipLaunchKernelGGL(k_trtri_v0, dim3(nbatch), dim3(256), 0, c->stream, L); }
+    } else if (multi_cu) {
+        std::vector<int> hst(nbatch), hjit(nbatch, 0);
+        for (int attempt = 0;; attempt++) {
+            launch_assemble();
+            for (int k = 0; k < nt64; k++) {
+                { Launcher l(c, KID_CI_PANEL); hipLaunchKernelGGL(k_ci_panel, dim3(nt64, nbatch), dim3(MC_THREADS), 0, c->stream, L, k, inv ? 1 : 0); }
+                if (nt64 > 1) { Launcher l(c, KID_CI_TRSM); hipLaunchKernelGGL(k_ci_trsm, dim3(nt64 - 1, nbatch), dim3(MC_THREADS), 0, c->stream, L, k, inv ? 1 : 0); }
+            }
+            hipLaunchKernelGGL(k_ci_finish, dim3(nbatch), dim3(256), 0, c->stream, L);
+            HIPCHK(c, hipMemcpyAsync(hst.data(), c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            bool retry = false;
+            for (int bb = 0; bb < nbatch; bb++)
+                if (hst[bb] == -2) {   // ref c_inference_exact.cpp:99-111: add the noise again, at most 10 times
+                    if (hjit[bb] >= 10) hst[bb] = -1;
+                    else { hjit[bb]++; hst[bb] = 0; retry = true; }
+                } else if (hst[bb] >= 0) hst[bb] = 0;
+            if (!retry) {
+                bool fix = false;
+                for (int bb = 0; bb < nbatch; bb++) fix = fix || (hjit[bb] >= 10 && hst[bb] == -1);
+                if (fix) {   // final failures: publish -1
+                    std::vector<int> cur(nbatch);
+                    HIPCHK(c, hipMemcpy(cur.data(), c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost));
+                    for (int bb = 0; bb < nbatch; bb++) if (cur[bb] == -2) cur[bb] = -1;
+                    HIPCHK(c, hipMemcpy(c->d_status, cur.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice));
+                }
+                break;
+            }
+            // failed problems restart with one more noise addition; finished ones are recomputed identically
+            std::vector<int> cur(nbatch);
+            HIPCHK(c, hipMemcpy(cur.data(), c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost));
+            for (int bb = 0; bb < nbatch; bb++) if (cur[bb] == -2 || cur[bb] >= 0) cur[bb] = (hst[bb] == -1) ? -1 : 0;
+            HIPCHK(c, hipMemcpy(c->d_status, cur.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(c->d_jit, hjit.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice));
+            // logdet accumulators restart
+            std::vector<double> zero4(4 * (size_t)nbatch, 0.0);
+            HIPCHK(c, hipMemcpy(L.scal, zero4.data(), sizeof(double) * 4 * nbatch, hipMemcpyHostToDevice));
+            (void)attempt;
+        }
     } else {
+        launch_assemble();
         Launcher l(c, KID_CHOLINV);
-        // more patients than CUs: 8-wave workgroups, two per CU (serial phases overlap); else 16 waves for latency
         // more patients than CUs: 4-wave workgroups, two per CU (the serial diagonal phase of one overlaps the
         // MFMA phase of the other); else 8 waves for the lowest latency per patient
         const int shape = c->cholinv_nw ? c->cholinv_nw : (nbatch > c->num_cu ? 44 : 84);
@@ -266,6 +312,7 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     c->stream = c->own_stream;
     { const char *e = getenv("MEDGP_V0"); c->use_v0 = e && e[0] == '1'; }
     { const char *e = getenv("MEDGP_CHOLINV_NW"); c->cholinv_nw = e ? atoi(e) : 0; }
+    { const char *e = getenv("MEDGP_MULTI_CU"); c->force_mc = e ? atoi(e) : 0; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->num_cu = pr.multiProcessorCount; }
     *out = c;
     return MEDGP_OK;
@@ -327,6 +374,7 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     if ((rc = dalloc(c, &c->d_prior_on, S))) return rc;
     if ((rc = dalloc(c, &c->d_bslot, B))) return rc;
     if ((rc = dalloc(c, &c->d_status, B))) return rc;
+    if ((rc = dalloc(c, &c->d_jit, B))) return rc;
     if ((rc = dalloc(c, &c->d_theta, B * H))) return rc;
     if ((rc = dalloc(c, &c->d_nlml, B))) return rc;
     if ((rc = dalloc(c, &c->d_grad, B * H))) return rc;
@@ -342,6 +390,9 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     L.slab_stride = (size_t)3 * Q * L.slab_R * L.slab_C;
     if ((rc = dalloc(c, &slab, B * L.slab_stride))) return rc;
     if ((rc = dalloc(c, &wdiag, B * ldn))) return rc;
+    double *xk;
+    if ((rc = dalloc(c, &xk, B * 64 * 64))) return rc;
+    L.xk = xk; L.jit = c->d_jit;
     if ((rc = dalloc(c, &hyp, B * L.hyp_stride))) return rc;
     if ((rc = dalloc(c, &cs, B * Q * ldn))) return rc;
     if ((rc = dalloc(c, &sn, B * Q * ldn))) return rc;

@@ -43,6 +43,8 @@ struct MedgpDev {
     double *z, *alpha;       // [batch][ldn]
     double *scal;            // [batch][4]: logdet, quad, -, -
     int *status;             // [batch]
+    int *jit;                // [batch] jitter rounds applied so far (extra noise additions in the assembly)
+    double *xk;              // [batch][64*64] L_kk^-1 of the current panel (multi-CU factorisation)
     double *S, *SM, *SV;     // [batch][Q*D*D]
     double *slab;            // [batch][3][Q][slab_R][slab_C] piecewise block sums written by k_wgrad
     double *wdiag;           // [batch][ldn] diag(W)
