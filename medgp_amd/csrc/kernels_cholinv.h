@@ -23,6 +23,20 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define CI_KC 16          // k-columns staged per barrier
+
+// Diagnostic build only (-DMEDGP_STAMPS, never shipped): per-phase s_memtime sums per wave, written to a debug
+// buffer that no other code reads (guide section 7, "In-kernel stamps").
+#ifdef MEDGP_STAMPS
+#define STAMP(idx)                                                                                 \
+    do {                                                                                           \
+        unsigned long long t_;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+        st_acc[idx] += t_ - st_last;                                                               \
+        st_last = t_;                                                                              \
+    } while (0)
+#else
+#define STAMP(idx) do {} while (0)
+#endif
 #define CI_THREADS 1024   // largest workgroup (16 waves: 8 blocks x 2 halves per pass)
 
 struct CholInvSmem {
@@ -34,6 +48,8 @@ struct CholInvSmem {
     double zacc[64];               // L[C_k, 0:64k] z[0:64k]
     double rhs[64];
     double zk[64];                 // z of the current panel (for the in-step alpha accumulation)
+    double zs[1024];               // z history kept in LDS for n <= 1024: the in-loop z product then issues no
+                                   // global loads, whose wait (vmcnt) would also drain the operand prefetch
     double rdiag[16];              // 1 / diag of the current 16x16 tile
     double red[16];
     double logdet;
@@ -204,6 +220,10 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 
     if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
     __syncthreads();
+#ifdef MEDGP_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
 
     for (int k = 0; k < nb; k++) {
         const int c0 = 64 * k;                       // first column of the panel
@@ -234,6 +254,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                         for (int r = 0; r < 4; r++) acc[ct][u][r] = -Lb[(size_t)(row0 + 16 * u + li) * ld + c0 + 16 * ct + 4 * r + g];
                     }
                 }
+            STAMP(0);   // init loads issued
             double zsum = 0.0;
             // ---- GEMM over the history, B chunk (L[C_k rows]) staged through LDS, double buffered
             if (nch > 0) {
@@ -287,16 +308,24 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     }
                     // z history product (pass 0 only): wave 15, lane = panel column
                     if (pass == 0 && wave == NW - 1) {
+                        if (npad <= 1024) {
 #pragma unroll
-                        for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * zz[c * CI_KC + kk];
+                            for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * sm.zs[c * CI_KC + kk];
+                        } else {
+#pragma unroll
+                            for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * zz[c * CI_KC + kk];
+                        }
                     }
                     if (c + 1 < nch) {
 #pragma unroll
                         for (int e = 0; e < SPT; e++) sm.Bs[buf ^ 1][srow][scol + e] = bnext[e];
                     }
+                    STAMP(1);   // MFMA + operand loads of this chunk
                     __syncthreads();
+                    STAMP(7);   // chunk barrier wait
                 }
             }
+            STAMP(1);   // history GEMM (incl. chunk barriers)
             if (pass == 0) {
                 // diagonal block (block index 0 = waves 0,1) -> LDS, factor, invert
                 if (wblk == 0) {
@@ -309,6 +338,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 }
                 if (wave == NW - 1) sm.zacc[lane] = zsum;
                 __syncthreads();
+                STAMP(2);   // wait for the slowest GEMM wave
                 if (wave == 0) {
                     diag_factor_wave(sm, lane);
                     if (!sm.fail) {
@@ -319,6 +349,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                         for (int cc = 0; cc <= lane; cc++) s += sm.Xk[lane][cc] * sm.rhs[cc];
                         zz[c0 + lane] = s;
                         sm.zk[lane] = s;
+                        if (c0 + lane < 1024) sm.zs[c0 + lane] = s;
                         if (want_inv) {
                             // alpha = U z accumulated panel by panel; the diagonal block U_kk = L_kk^-T opens rows C_k
                             __builtin_amdgcn_wave_barrier();
@@ -329,6 +360,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     }
                 }
                 __syncthreads();
+                STAMP(3);   // diagonal factor (wave 0) / waiting for it
                 if (sm.fail) return false;
                 // store L_kk (lower) and U_kk = L_kk^-T (upper, zeros below)
                 for (int e = tid; e < 64 * 64; e += NT) {
@@ -341,6 +373,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
             //        t = acc[ct] + sum_{cp<ct} L(ct,cp) out[cp];   out[ct] = (-X(ct,ct)) t
             // The diagonal-block owner (pass 0, block 0) solves for the identity instead: its rows of the panel
             // are U_kk = L_kk^-T, the diagonal block of the inverse factor.
+            STAMP(4);   // L_kk / U_kk stores
             // ---- triangular solve as GEMM: out^T[ct] = sum_{ct' <= ct} (-Xk[ct, ct']) acc^T[ct'], then store
             //      (measured faster than substituting tile by tile: four independent accumulator chains per unit)
             if (active && !(pass == 0 && wblk == 0)) {
@@ -384,9 +417,17 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     }
                 }
             }
+            STAMP(5);   // panel solve + stores
             __syncthreads();   // stores of this step visible to the whole workgroup before the next history read
+            STAMP(6);   // end-of-step barrier
         }
     }
+#ifdef MEDGP_STAMPS
+    if (lane == 0 && b < 64) {
+        unsigned long long *dbg = (unsigned long long *)(L.slab + (size_t)b * L.slab_stride);
+        for (int e = 0; e < 8; e++) dbg[(tid >> 6) * 8 + e] = st_acc[e];
+    }
+#endif
     return true;
 }
 

@@ -245,6 +245,9 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
         else hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, c->stream, L, inv ? 1 : 0);
     }
     int from_slab = 0;
+#ifdef MEDGP_STAMPS
+    if (getenv("MEDGP_DBG_NOWGRAD")) { HIPCHK(c, hipGetLastError()); return MEDGP_OK; }
+#endif
     if (flag_grad) {
         const dim3 tg(nbatch, tri(nt64)), tb(WG_THREADS);
         from_slab = 1;
@@ -621,6 +624,15 @@ int medgp_fit_predict_batch(medgp_ctx *c, int nbatch, const int32_t *slots, cons
     if (c && nbatch > c->max_batch) return fail(c, MEDGP_ERR_CAPACITY, "nbatch %d outside [1, %d]", nbatch, c->max_batch);
     return fit_predict_impl(c, nbatch, slots, theta, 1, meta2, t2, mean, var, status);
 }
+
+#ifdef MEDGP_STAMPS
+// diagnostic build only: copy out the stamp words k_cholinv left in the slab of batch entry b
+int medgp_debug_read_slab(medgp_ctx *c, int b, void *out, int nbytes) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->dev.slab + (size_t)b * c->dev.slab_stride, nbytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 
 int medgp_profile_enable(medgp_ctx *c, int enable) {
     if (!c) return MEDGP_ERR_ARG;
