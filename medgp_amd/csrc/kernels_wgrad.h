@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
                 for (int pl = 0; pl < 3; pl++)
 #pragma unroll
                     for (int q = 0; q < QT; q++) {
-                        fl[lane] = (pl == 0) ? sS[q] : (pl == 1 ? sM[q] : sV[q]);
+                        fl[lane] = (pl == 0) ? sS[q] : (pl == 1 ? -wq[q] * sM[q] : -2.0 * cq[q] * sV[q]);
                         __builtin_amdgcn_wave_barrier();
                         if (leader && mj >= 0) {
                             double s = 0.0;
@@ -168,16 +168,18 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
         const bool valid = jv && (j <= i);
         wv = valid ? ((mi == mj && j < i) ? 2.0 * wv : wv) : 0.0;
         const double dt = ti - tj, dd = dt * dt;
+        // running sums hold  sum w E cd,  sum w E sd dt,  sum w E cd dt^2 ; the constant factors
+        // (-w_q, -2 c_q) are applied once per flush -- 3 VALU less per (pair, component)
 #pragma unroll
         for (int q = 0; q < QT; q++) {
             const double ci = csb[q * ld + i], si = snb[q * ld + i];   // wave-uniform loads
-            const double E = exp_neg(cq[q] * dd);
+            const double we = wv * exp_neg(cq[q] * dd);
             const double cd = ci * csj[q] + si * snj[q];
             const double sd = si * csj[q] - ci * snj[q];
-            const double k = cd * E;
-            sS[q] += wv * k;
-            sM[q] += wv * (-(wq[q] * dt * sd) * E);
-            sV[q] += wv * (-2.0 * cq[q] * dd * k);
+            const double p = we * cd;
+            sS[q] += p;
+            sM[q] += (we * sd) * dt;
+            sV[q] += p * dd;
         }
     }
 }
