@@ -62,6 +62,9 @@ struct medgp_ctx {
     int cholinv_nw = 0;       // MEDGP_CHOLINV_NW=44|84 forces the workgroup shape (0 = auto)
     int force_mc = 0;         // MEDGP_MULTI_CU=1 forces / -1 forbids the multi-CU factorisation (0 = auto)
     int num_cu = 256;
+    int nsplit = 1;           // MEDGP_STREAMS=2 splits large batches over two streams (measured: 98.9k vs 104.6k evals/s -> off)
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     std::vector<EvPair> events;
     double prof_ms[KID_COUNT] = {0};
     int64_t prof_n[KID_COUNT] = {0};
@@ -113,17 +116,18 @@ int num_cov(int kidx, int Q, int D, int R) {
 struct Launcher {
     medgp_ctx *c;
     int kid;
+    hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
-    Launcher(medgp_ctx *c_, int kid_) : c(c_), kid(kid_) {
+    Launcher(medgp_ctx *c_, int kid_, hipStream_t st_ = nullptr) : c(c_), kid(kid_), st(st_ ? st_ : c_->stream) {
         if (c->profiling) {
             (void)hipEventCreate(&a);
             (void)hipEventCreate(&b);
-            (void)hipEventRecord(a, c->stream);
+            (void)hipEventRecord(a, st);
         }
     }
     ~Launcher() {
         if (c->profiling) {
-            (void)hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, st);
             if (kid >= 0) c->events.push_back({kid, a, b});
             else { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
         }
@@ -166,25 +170,24 @@ int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out) {
 
 inline int tri(int n) { return n * (n + 1) / 2; }
 
-// the evaluation pipeline; everything is asynchronous on c->stream
-int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, int flag_grad, bool need_inverse, int min_n,
-                 double *nlml_dev, double *grad_dev, int32_t *status_dev) {
-    const MedgpDev &L = c->dev;
+// one kernel chain for the batch entries described by L (possibly a shifted view of c->dev) on `stream`
+int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nbatch, int max_n, const double *theta_dev,
+                     int flag_grad, bool need_inverse, int min_n, double *nlml_dev, double *grad_dev, int32_t *status_dev) {
     const int nt64 = medgp_roundup(std::max(max_n, 1), 64) / 64;
-    { Launcher l(c, KID_PREP); hipLaunchKernelGGL(k_prep, dim3(nbatch), dim3(256), 0, c->stream, L, theta_dev, min_n); }
+    { Launcher l(c, KID_PREP, stream); hipLaunchKernelGGL(k_prep, dim3(nbatch), dim3(256), 0, stream, L, theta_dev, min_n); }
     auto launch_assemble = [&]() {
-        Launcher l(c, KID_ASSEMBLE);
+        Launcher l(c, KID_ASSEMBLE, stream);
         const dim3 tg(tri(nt64), nbatch), tb(256);
         switch (c->use_v0 ? 0 : L.Q) {
-        case 1: hipLaunchKernelGGL(k_assemble_t<1>, tg, tb, 0, c->stream, L); break;
-        case 2: hipLaunchKernelGGL(k_assemble_t<2>, tg, tb, 0, c->stream, L); break;
-        case 3: hipLaunchKernelGGL(k_assemble_t<3>, tg, tb, 0, c->stream, L); break;
-        case 4: hipLaunchKernelGGL(k_assemble_t<4>, tg, tb, 0, c->stream, L); break;
-        case 5: hipLaunchKernelGGL(k_assemble_t<5>, tg, tb, 0, c->stream, L); break;
-        case 6: hipLaunchKernelGGL(k_assemble_t<6>, tg, tb, 0, c->stream, L); break;
-        case 7: hipLaunchKernelGGL(k_assemble_t<7>, tg, tb, 0, c->stream, L); break;
-        case 8: hipLaunchKernelGGL(k_assemble_t<8>, tg, tb, 0, c->stream, L); break;
-        default: hipLaunchKernelGGL(k_assemble_v0, tg, tb, 0, c->stream, L); break;
+        case 1: hipLaunchKernelGGL(k_assemble_t<1>, tg, tb, 0, stream, L); break;
+        case 2: hipLaunchKernelGGL(k_assemble_t<2>, tg, tb, 0, stream, L); break;
+        case 3: hipLaunchKernelGGL(k_assemble_t<3>, tg, tb, 0, stream, L); break;
+        case 4: hipLaunchKernelGGL(k_assemble_t<4>, tg, tb, 0, stream, L); break;
+        case 5: hipLaunchKernelGGL(k_assemble_t<5>, tg, tb, 0, stream, L); break;
+        case 6: hipLaunchKernelGGL(k_assemble_t<6>, tg, tb, 0, stream, L); break;
+        case 7: hipLaunchKernelGGL(k_assemble_t<7>, tg, tb, 0, stream, L); break;
+        case 8: hipLaunchKernelGGL(k_assemble_t<8>, tg, tb, 0, stream, L); break;
+        default: hipLaunchKernelGGL(k_assemble_v0, tg, tb, 0, stream, L); break;
         }
     };
     const bool inv = flag_grad || need_inverse;
@@ -194,19 +197,19 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
     const bool multi_cu = !c->use_v0 && (c->force_mc > 0 || (c->force_mc == 0 && nt64 >= 2 && (nbatch <= c->num_cu / 2 || (nbatch < c->num_cu && nt64 >= 16))));
     if (c->use_v0) {
         launch_assemble();
-        { Launcher l(c, KID_POTRF); hipLaunchKernelGGL(k_potrf_v0, dim3(nbatch), dim3(256), 0, c->stream, L); }
-        if (inv) { Launcher l(c, KID_TRTRI); hipLaunchKernelGGL(k_trtri_v0, dim3(nbatch), dim3(256), 0, c->stream, L); }
+        { Launcher l(c, KID_POTRF, stream); hipLaunchKernelGGL(k_potrf_v0, dim3(nbatch), dim3(256), 0, stream, L); }
+        if (inv) { Launcher l(c, KID_TRTRI, stream); hipLaunchKernelGGL(k_trtri_v0, dim3(nbatch), dim3(256), 0, stream, L); }
     } else if (multi_cu) {
         std::vector<int> hst(nbatch), hjit(nbatch, 0);
         for (int attempt = 0;; attempt++) {
             launch_assemble();
             for (int k = 0; k < nt64; k++) {
-                { Launcher l(c, KID_CI_PANEL); hipLaunchKernelGGL(k_ci_panel, dim3(nt64, nbatch), dim3(MC_THREADS), 0, c->stream, L, k, inv ? 1 : 0); }
-                if (nt64 > 1) { Launcher l(c, KID_CI_TRSM); hipLaunchKernelGGL(k_ci_trsm, dim3(nt64 - 1, nbatch), dim3(MC_THREADS), 0, c->stream, L, k, inv ? 1 : 0); }
+                { Launcher l(c, KID_CI_PANEL, stream); hipLaunchKernelGGL(k_ci_panel, dim3(nt64, nbatch), dim3(MC_THREADS), 0, stream, L, k, inv ? 1 : 0); }
+                if (nt64 > 1) { Launcher l(c, KID_CI_TRSM, stream); hipLaunchKernelGGL(k_ci_trsm, dim3(nt64 - 1, nbatch), dim3(MC_THREADS), 0, stream, L, k, inv ? 1 : 0); }
             }
-            hipLaunchKernelGGL(k_ci_finish, dim3(nbatch), dim3(256), 0, c->stream, L);
-            HIPCHK(c, hipMemcpyAsync(hst.data(), c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipLaunchKernelGGL(k_ci_finish, dim3(nbatch), dim3(256), 0, stream, L);
+            HIPCHK(c, hipMemcpyAsync(hst.data(), L.status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, stream));
+            HIPCHK(c, hipStreamSynchronize(stream));
             bool retry = false;
             for (int bb = 0; bb < nbatch; bb++)
                 if (hst[bb] == -2) {   // ref c_inference_exact.cpp:99-111: add the noise again, at most 10 times
@@ -218,18 +221,18 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
                 for (int bb = 0; bb < nbatch; bb++) fix = fix || (hjit[bb] >= 10 && hst[bb] == -1);
                 if (fix) {   // final failures: publish -1
                     std::vector<int> cur(nbatch);
-                    HIPCHK(c, hipMemcpy(cur.data(), c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost));
+                    HIPCHK(c, hipMemcpy(cur.data(), L.status, sizeof(int) * nbatch, hipMemcpyDeviceToHost));
                     for (int bb = 0; bb < nbatch; bb++) if (cur[bb] == -2) cur[bb] = -1;
-                    HIPCHK(c, hipMemcpy(c->d_status, cur.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice));
+                    HIPCHK(c, hipMemcpy(L.status, cur.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice));
                 }
                 break;
             }
             // failed problems restart with one more noise addition; finished ones are recomputed identically
             std::vector<int> cur(nbatch);
-            HIPCHK(c, hipMemcpy(cur.data(), c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(cur.data(), L.status, sizeof(int) * nbatch, hipMemcpyDeviceToHost));
             for (int bb = 0; bb < nbatch; bb++) if (cur[bb] == -2 || cur[bb] >= 0) cur[bb] = (hst[bb] == -1) ? -1 : 0;
-            HIPCHK(c, hipMemcpy(c->d_status, cur.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice));
-            HIPCHK(c, hipMemcpy(c->d_jit, hjit.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(L.status, cur.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(L.jit, hjit.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice));
             // logdet accumulators restart
             std::vector<double> zero4(4 * (size_t)nbatch, 0.0);
             HIPCHK(c, hipMemcpy(L.scal, zero4.data(), sizeof(double) * 4 * nbatch, hipMemcpyHostToDevice));
@@ -237,12 +240,12 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
         }
     } else {
         launch_assemble();
-        Launcher l(c, KID_CHOLINV);
+        Launcher l(c, KID_CHOLINV, stream);
         // more patients than CUs: 4-wave workgroups, two per CU (the serial diagonal phase of one overlaps the
         // MFMA phase of the other); else 8 waves for the lowest latency per patient
         const int shape = c->cholinv_nw ? c->cholinv_nw : (nbatch > c->num_cu ? 44 : 84);
-        if (shape == 44) hipLaunchKernelGGL((k_cholinv<4, 4>), dim3(nbatch), dim3(256), 0, c->stream, L, inv ? 1 : 0);
-        else hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, c->stream, L, inv ? 1 : 0);
+        if (shape == 44) hipLaunchKernelGGL((k_cholinv<4, 4>), dim3(nbatch), dim3(256), 0, stream, L, inv ? 1 : 0);
+        else hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, inv ? 1 : 0);
     }
     int from_slab = 0;
 #ifdef MEDGP_STAMPS
@@ -251,30 +254,69 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
     if (flag_grad) {
         const dim3 tg(nbatch, tri(nt64)), tb(WG_THREADS);
         from_slab = 1;
-        Launcher *lw = new Launcher(c, KID_WGRAD);
+        Launcher *lw = new Launcher(c, KID_WGRAD, stream);
         switch (c->use_v0 ? 0 : L.Q) {
-        case 1: hipLaunchKernelGGL(k_wgrad<1>, tg, tb, 0, c->stream, L); break;
-        case 2: hipLaunchKernelGGL(k_wgrad<2>, tg, tb, 0, c->stream, L); break;
-        case 3: hipLaunchKernelGGL(k_wgrad<3>, tg, tb, 0, c->stream, L); break;
-        case 4: hipLaunchKernelGGL(k_wgrad<4>, tg, tb, 0, c->stream, L); break;
-        case 5: hipLaunchKernelGGL(k_wgrad<5>, tg, tb, 0, c->stream, L); break;
-        case 6: hipLaunchKernelGGL(k_wgrad<6>, tg, tb, 0, c->stream, L); break;
-        case 7: hipLaunchKernelGGL(k_wgrad<7>, tg, tb, 0, c->stream, L); break;
-        case 8: hipLaunchKernelGGL(k_wgrad<8>, tg, tb, 0, c->stream, L); break;
+        case 1: hipLaunchKernelGGL(k_wgrad<1>, tg, tb, 0, stream, L); break;
+        case 2: hipLaunchKernelGGL(k_wgrad<2>, tg, tb, 0, stream, L); break;
+        case 3: hipLaunchKernelGGL(k_wgrad<3>, tg, tb, 0, stream, L); break;
+        case 4: hipLaunchKernelGGL(k_wgrad<4>, tg, tb, 0, stream, L); break;
+        case 5: hipLaunchKernelGGL(k_wgrad<5>, tg, tb, 0, stream, L); break;
+        case 6: hipLaunchKernelGGL(k_wgrad<6>, tg, tb, 0, stream, L); break;
+        case 7: hipLaunchKernelGGL(k_wgrad<7>, tg, tb, 0, stream, L); break;
+        case 8: hipLaunchKernelGGL(k_wgrad<8>, tg, tb, 0, stream, L); break;
         default: from_slab = 0; break;   // Q > 8 (or MEDGP_V0): generic kernels below
         }
         if (from_slab) delete lw; else { lw->kid = -1; delete lw; }
         if (!from_slab) {
-            { Launcher l(c, KID_LAUUM); hipLaunchKernelGGL(k_lauum_v0, dim3(tri(nt64), nbatch), dim3(256), 0, c->stream, L); }
+            { Launcher l(c, KID_LAUUM, stream); hipLaunchKernelGGL(k_lauum_v0, dim3(tri(nt64), nbatch), dim3(256), 0, stream, L); }
             const int nbins = L.Q * tri(L.D);
-            { Launcher l(c, KID_GRADBINS); hipLaunchKernelGGL(k_gradbins_v0, dim3((nbins + 255) / 256, nbatch), dim3(256), 0, c->stream, L); }
+            { Launcher l(c, KID_GRADBINS, stream); hipLaunchKernelGGL(k_gradbins_v0, dim3((nbins + 255) / 256, nbatch), dim3(256), 0, stream, L); }
         }
     }
     if (nlml_dev) {
-        Launcher l(c, KID_EPILOGUE);
-        hipLaunchKernelGGL(k_epilogue, dim3(nbatch), dim3(256), 0, c->stream, L, theta_dev, flag_grad, from_slab, nlml_dev, grad_dev, (int *)status_dev);
+        Launcher l(c, KID_EPILOGUE, stream);
+        hipLaunchKernelGGL(k_epilogue, dim3(nbatch), dim3(256), 0, stream, L, theta_dev, flag_grad, from_slab, nlml_dev, grad_dev, (int *)status_dev);
     }
     HIPCHK(c, hipGetLastError());
+    return MEDGP_OK;
+}
+
+
+// view of the batch-indexed buffers starting at entry b0
+MedgpDev shifted_view(const MedgpDev &L, int b0) {
+    MedgpDev V = L;
+    const size_t ld = L.ldn, Q = L.Q, D = L.D;
+    V.bslot = L.bslot + b0;
+    V.hyp = L.hyp + (size_t)b0 * L.hyp_stride;
+    V.cs = L.cs + (size_t)b0 * Q * ld; V.sn = L.sn + (size_t)b0 * Q * ld;
+    V.Kmat = L.Kmat + (size_t)b0 * ld * ld; V.Linv = L.Linv + (size_t)b0 * ld * ld;
+    V.z = L.z + (size_t)b0 * ld; V.alpha = L.alpha + (size_t)b0 * ld; V.wdiag = L.wdiag + (size_t)b0 * ld;
+    V.scal = L.scal + (size_t)b0 * 4; V.status = L.status + b0; V.jit = L.jit + b0; V.xk = L.xk + (size_t)b0 * 64 * 64;
+    V.S = L.S + (size_t)b0 * Q * D * D; V.SM = L.SM + (size_t)b0 * Q * D * D; V.SV = L.SV + (size_t)b0 * Q * D * D;
+    V.slab = L.slab + (size_t)b0 * L.slab_stride;
+    return V;
+}
+
+// The evaluation pipeline; everything is asynchronous on c->stream.  Optional (MEDGP_STREAMS=2): large batches split
+// in two halves on two auxiliary streams so that k_cholinv of one half co-runs with the VALU-heavy kernels of the
+// other half.  Measured on MI355X at the headline shape: no gain (98.9k vs 104.6k evals/s), so it is off by default.
+int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, int flag_grad, bool need_inverse, int min_n,
+                 double *nlml_dev, double *grad_dev, int32_t *status_dev) {
+    const bool split = !c->use_v0 && c->nsplit >= 2 && nbatch >= 2 * c->num_cu && c->aux[0] && c->aux[1];
+    if (!split) return run_pipeline_one(c, c->stream, c->dev, nbatch, max_n, theta_dev, flag_grad, need_inverse, min_n, nlml_dev, grad_dev, status_dev);
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    const int h = (nbatch / 2 + 1) & ~1;   // even: keeps the (b & 1) wave mirroring of k_cholinv consistent
+    const int b0[2] = {0, h}, nb[2] = {h, nbatch - h};
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(c, hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
+        MedgpDev V = shifted_view(c->dev, b0[i]);
+        int rc = run_pipeline_one(c, c->aux[i], V, nb[i], max_n, theta_dev + (size_t)b0[i] * c->H, flag_grad, need_inverse, min_n,
+                                  nlml_dev ? nlml_dev + b0[i] : nullptr, grad_dev ? grad_dev + (size_t)b0[i] * c->H : nullptr,
+                                  status_dev ? status_dev + b0[i] : nullptr);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_join[i], c->aux[i]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
+    }
     return MEDGP_OK;
 }
 
@@ -316,6 +358,12 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     { const char *e = getenv("MEDGP_V0"); c->use_v0 = e && e[0] == '1'; }
     { const char *e = getenv("MEDGP_CHOLINV_NW"); c->cholinv_nw = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_MULTI_CU"); c->force_mc = e ? atoi(e) : 0; }
+    { const char *e = getenv("MEDGP_STREAMS"); c->nsplit = e ? atoi(e) : 1; }
+    for (int i = 0; i < 2; i++) {
+        (void)hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
+    }
+    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->num_cu = pr.multiProcessorCount; }
     *out = c;
     return MEDGP_OK;
@@ -327,6 +375,11 @@ void medgp_destroy(medgp_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     free_all(c);
+    for (int i = 0; i < 2; i++) {
+        if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
