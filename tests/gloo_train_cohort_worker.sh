@@ -1,0 +1,13 @@
+#!/bin/bash
+# stand-in for medgp_train in the CPU test of medgp_amd.train_cohort: writes a train_hyp file per patient of the shard
+# usage: ... --cfg CFG --pan-list FILE --device D --max-batch B
+while [ $# -gt 0 ]; do case "$1" in --cfg) CFG=$2; shift 2;; --pan-list) PL=$2; shift 2;; *) shift;; esac; done
+python3 - "$CFG" "$PL" <<'PY'
+import json, sys, numpy as np, os, zlib
+cfg = json.load(open(sys.argv[1]))
+Q, D, R = int(cfg["Q"]), int(cfg["D"]), int(cfg["R"])
+H = D + Q * (D * R + 2 + D)
+for pan in open(sys.argv[2]).read().split():
+    rng = np.random.default_rng(zlib.crc32(pan.encode()))
+    rng.normal(size=H).tofile(os.path.join(cfg["exp_train_dir"], f"train_hyp_{pan}.bin"))
+PY

@@ -51,3 +51,31 @@ def test_two_rank_gloo_sharded_evaluation_matches_single_process():
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "GLOO_SHARD_OK" in out.stdout
+
+
+def test_train_cohort_launcher_shards_and_gathers_over_gloo(tmp_path):
+    """medgp_amd.train_cohort on 2 CPU ranks (gloo) with a stand-in trainer: LPT sharding of the patient list,
+    one trainer invocation per rank, all-gather of the trained hypers into cohort_train_hyp.npy."""
+    import json
+    import zlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from exp_fixture import make_experiment
+    pans = [f"P{k:03d}" for k in range(7)]
+    ex = make_experiment(tmp_path, pans, D=2, Q=2, R=2, N=[20, 31, 24, 40, 22, 35, 28])
+    plist = tmp_path / "pans.txt"
+    plist.write_text("\n".join(pans) + "\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", "-m", "medgp_amd.train_cohort",
+                          "--cfg", ex["cfg"], "--pan-list", str(plist), "--gather", "--backend", "gloo",
+                          "--exe", os.path.join(ROOT, "tests", "gloo_train_cohort_worker.sh")],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = np.load(os.path.join(ex["dirs"]["train"], "cohort_train_hyp.npy"))
+    H = 2 + 2 * (2 * 2 + 2 + 2)
+    assert got.shape == (7, H + 2) and np.array_equal(got[:, 0], np.arange(7)) and np.all(got[:, 1] == 1)
+    for k, pan in enumerate(pans):
+        exp = np.random.default_rng(zlib.crc32(pan.encode())).normal(size=H)
+        assert np.array_equal(got[k, 2:], exp)
+    shards = [open(os.path.join(ex["dirs"]["train"], f"pan_shard_rank{r}.txt")).read().split() for r in range(2)]
+    assert sorted(shards[0] + shards[1]) == pans and shards[0] and shards[1]

@@ -253,3 +253,65 @@ def test_device_pointer_api_matches_host_api():
     assert np.array_equal(s_d.cpu().numpy(), st)
     ctx.set_stream(None)
     ctx.close()
+
+
+def test_baseline_config2_full_size():
+    """BASELINE config 2: 256 synthetic patients x N=256, D=2, fp64, one batch on one MI355X."""
+    D, N, Q, R, P = 2, 256, 5, 2, 256
+    pts, th = synth.cohort(202, P, D, N, Q=Q, R=R)
+    ctx = make_ctx(7, Q, D, R, pts)
+    nlml, grad, st = ctx.nlml_grad(np.arange(P), th, True)
+    assert np.all(st == 0) and np.all(np.isfinite(nlml)) and np.all(np.isfinite(grad))
+    for p in (0, 17, 255):
+        ref = O.nlml_grad(7, Q, D, R, *pts[p], th[p])
+        assert_parity(nlml[p], grad[p], ref, f"p{p}")
+    ctx.close()
+
+
+def test_config5_shape_and_many_components():
+    """D = 64 outputs (BASELINE config 5's width; B_q table 164 KB) at a reduced N, and Q = 9 > 8 which takes
+    the generic (non-templated) assembly / gradient kernels."""
+    for (D, N, Q, R) in ((64, 320, 5, 8), (3, 150, 9, 2)):
+        pts, th = synth.cohort(303, 2, D, N, Q=Q, R=R)
+        ctx = make_ctx(7, Q, D, R, pts)
+        nlml, grad, st = ctx.nlml_grad([0, 1], th, True)
+        for p in range(2):
+            ref = O.nlml_grad(7, Q, D, R, *pts[p], th[p], nthreads=4)
+            assert st[p] == 0
+            assert_parity(nlml[p], grad[p], ref, f"D{D} Q{Q} p{p}")
+        ctx.close()
+
+
+def test_multi_cu_and_single_workgroup_factorisations_agree(monkeypatch):
+    """The multi-CU panel path (few large patients) and the one-workgroup-per-patient path are two schedules of the
+    same arithmetic: results must agree to rounding, and each must match the oracle."""
+    D, N, Q, R = 24, 700, 5, 8
+    pts, th = synth.cohort(404, 2, D, N, Q=Q, R=R)
+    out = {}
+    for mode in ("1", "-1"):
+        monkeypatch.setenv("MEDGP_MULTI_CU", mode)
+        ctx = make_ctx(7, Q, D, R, pts)
+        out[mode] = ctx.nlml_grad([0, 1], th, True)
+        ctx.close()
+    ref = O.nlml_grad(7, Q, D, R, *pts[0], th[0], nthreads=8)
+    for mode in out:
+        assert_parity(out[mode][0][0], out[mode][1][0], ref, f"mode{mode}")
+    np.testing.assert_allclose(out["1"][0], out["-1"][0], rtol=1e-12)
+
+
+def test_fit_predict_batch_matches_single_calls():
+    D, Q, R = 3, 3, 2
+    pts = [synth.patient(71, p, D, n) for p, n in enumerate((1, 2, 30, 77))]   # n = 1, 2: no n > 2 guard on this path
+    th = np.stack([synth.theta(71, p, 7, Q, D, R) for p in range(4)])
+    ctx = make_ctx(7, Q, D, R, pts)
+    m2 = np.array([0, 1, 2, 1], np.int32)
+    t2 = np.array([3.0, 50.0, 120.5, 77.25], np.float32)
+    mean, var, st = ctx.fit_predict_batch([0, 1, 2, 3], th, m2, t2)
+    assert np.all(st == 0)
+    for p in range(4):
+        rp = O.fit_predict(7, Q, D, R, *pts[p], th[p], m2[p:p + 1], t2[p:p + 1])
+        np.testing.assert_allclose(mean[p], rp["mean"][0], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(var[p], rp["var"][0], rtol=1e-5, atol=1e-6)
+        m1, v1, s1 = ctx.fit_predict(p, th[p], m2[p:p + 1], t2[p:p + 1])
+        assert m1[0] == mean[p] and v1[0] == var[p]
+    ctx.close()
