@@ -35,7 +35,15 @@ typedef double v2d __attribute__((ext_vector_type(2)));
         st_last = t_;                                                                              \
     } while (0)
 #else
-#define STAMP(idx) do {} while (0)
+// Shipped build: a stamp position keeps the SAME instruction (a scalar clock read + lgkmcnt(0), result unused) as a
+// scheduling anchor.  Measured: with these anchors hipcc keeps the accumulator tiles in registers through the MFMA
+// block (2.08 ms); with plain compiler fences or nothing it spills inside the block (2.48 - 2.53 ms, 512 x N=512).
+#define STAMP(idx)                                                                                 \
+    do {                                                                                           \
+        unsigned long long t_;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+        (void)t_;                                                                                  \
+    } while (0)
 #endif
 #define CI_THREADS 1024   // largest workgroup (16 waves: 8 blocks x 2 halves per pass)
 
@@ -214,7 +222,8 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
     // virtual wave id: odd batch entries mirror the wave order, so that when two workgroups share a CU the
     // heavy waves (diagonal owner, longest histories) of one sit beside the light waves of the other
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = (b & 1) ? (NW - 1 - (tid >> 6)) : (tid >> 6);
+    const int hwave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> scalar control flow + scalar bases
+    const int wave = (b & 1) ? (NW - 1 - hwave) : hwave;
     const int li = lane & 15, g = lane >> 4;
     const int wblk = wave / WPB, wsub = wave % WPB;
 
@@ -265,34 +274,23 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 double bnext[SPT];
 #pragma unroll
                 for (int e = 0; e < SPT; e++) { bnext[e] = Bsrc[e]; sm.Bs[0][srow][scol + e] = bnext[e]; }
-                v2d hn[UPW][2];
-                if (active && cfirst < nch) {
-#pragma unroll
-                    for (int u = 0; u < UPW; u++)
-#pragma unroll
-                        for (int h = 0; h < 2; h++)
-                            hn[u][h] = *(const v2d *)(Hist + (size_t)(row0 + 16 * u + li) * ld + cfirst * CI_KC + 8 * h + 2 * g);
-                }
                 __syncthreads();
                 for (int c = 0; c < nch; c++) {
                     const int buf = c & 1;
+                    // NO-PREFETCH experiment: operand loads for chunk c+1 are issued AFTER this chunk's MFMA block (below)
+                    v2d hc[UPW][2];
+                    if (active && c >= cfirst) {
+#pragma unroll
+                        for (int u = 0; u < UPW; u++)
+#pragma unroll
+                            for (int h = 0; h < 2; h++)
+                                hc[u][h] = *(const v2d *)(Hist + (size_t)(row0 + 16 * u + li) * ld + c * CI_KC + 8 * h + 2 * g);
+                    }
                     if (c + 1 < nch) {
 #pragma unroll
                         for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[(c + 1) * CI_KC + e];
                     }
                     if (active && c >= cfirst) {
-                        v2d hc[UPW][2];
-#pragma unroll
-                        for (int u = 0; u < UPW; u++)
-#pragma unroll
-                            for (int h = 0; h < 2; h++) hc[u][h] = hn[u][h];
-                        if (c + 1 < nch) {
-#pragma unroll
-                            for (int u = 0; u < UPW; u++)
-#pragma unroll
-                                for (int h = 0; h < 2; h++)
-                                    hn[u][h] = *(const v2d *)(Hist + (size_t)(row0 + 16 * u + li) * ld + (c + 1) * CI_KC + 8 * h + 2 * g);
-                        }
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
 #pragma unroll
@@ -316,11 +314,12 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                             for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * zz[c * CI_KC + kk];
                         }
                     }
+                    STAMP(4);   // MFMA block (+ z product)
                     if (c + 1 < nch) {
 #pragma unroll
                         for (int e = 0; e < SPT; e++) sm.Bs[buf ^ 1][srow][scol + e] = bnext[e];
                     }
-                    STAMP(1);   // MFMA + operand loads of this chunk
+                    STAMP(6);   // staging store (waits for this iteration's B loads)
                     __syncthreads();
                     STAMP(7);   // chunk barrier wait
                 }
@@ -338,7 +337,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 }
                 if (wave == NW - 1) sm.zacc[lane] = zsum;
                 __syncthreads();
-                STAMP(2);   // wait for the slowest GEMM wave
+                STAMP(0);   // wait for the slowest GEMM wave (folded into 0)
                 if (wave == 0) {
                     diag_factor_wave(sm, lane);
                     if (!sm.fail) {
@@ -373,7 +372,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
             //        t = acc[ct] + sum_{cp<ct} L(ct,cp) out[cp];   out[ct] = (-X(ct,ct)) t
             // The diagonal-block owner (pass 0, block 0) solves for the identity instead: its rows of the panel
             // are U_kk = L_kk^-T, the diagonal block of the inverse factor.
-            STAMP(4);   // L_kk / U_kk stores
+            STAMP(3);   // L_kk / U_kk stores (folded into diag)
             // ---- triangular solve as GEMM: out^T[ct] = sum_{ct' <= ct} (-Xk[ct, ct']) acc^T[ct'], then store
             //      (measured faster than substituting tile by tile: four independent accumulator chains per unit)
             if (active && !(pass == 0 && wblk == 0)) {
@@ -419,7 +418,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
             }
             STAMP(5);   // panel solve + stores
             __syncthreads();   // stores of this step visible to the whole workgroup before the next history read
-            STAMP(6);   // end-of-step barrier
+            STAMP(5);   // end-of-step barrier (folded into trsm)
         }
     }
 #ifdef MEDGP_STAMPS

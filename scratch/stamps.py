@@ -5,7 +5,7 @@ import medgp_amd
 from medgp_amd import capi, synth
 capi.lib_path = lambda: '/root/repo/scratch/libmedgp_hip_stamps.so'
 D,N,Q,R=24,512,5,8
-names=['init','gemm','wait_gemm','diag','store_kk','trsm','endbar','chunkbar']
+names=['init+wait','issue','ldwait','diag+st','mfma','trsm+end','stagest','chunkbar']
 for P in (512,):
     pts, th = synth.cohort(11, min(P,16), D, N, Q=Q, R=R)
     ctx = medgp_amd.Context(7, Q, D, R); ctx.reserve(P, N, P)
@@ -26,3 +26,15 @@ for P in (512,):
         for w in range(nw):
             print('   wave',w,' '.join(f"{names[e]}={100*a[w,e]/tot[w]:.0f}%" for e in range(8)))
     ctx.close()
+# wall time of the stamped build's kernel (HIP events) for comparison with the production build
+import time
+P=512
+pts, th = synth.cohort(11, 16, D, N, Q=Q, R=R)
+ctx = medgp_amd.Context(7, Q, D, R); ctx.reserve(P, N, P)
+for s in range(P): ctx.set_patient(s, *pts[s % 16])
+th = np.stack([th[s % 16] for s in range(P)])
+os.environ.pop('MEDGP_DBG_NOWGRAD', None)
+ctx.nlml_grad(np.arange(P), th, True)
+ctx.profile_enable(True)
+for _ in range(3): ctx.nlml_grad(np.arange(P), th, True)
+print('stamped build kernel times', {k: round(v[0]/3,3) for k,v in ctx.profile_read().items() if v[1]>0})
