@@ -22,7 +22,7 @@
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-#define CI_KC 16          // k-columns staged per barrier
+#define CI_KC 16          // k-columns staged per barrier (32 spills accumulators in the hot loop)
 
 // Diagnostic build only (-DMEDGP_STAMPS, never shipped): per-phase s_memtime sums per wave, written to a debug
 // buffer that no other code reads (guide section 7, "In-kernel stamps").
@@ -267,9 +267,9 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
             double zsum = 0.0;
             // ---- GEMM over the history, B chunk (L[C_k rows]) staged through LDS, double buffered
             if (nch > 0) {
-                // staging: 64 x 16 doubles per chunk, NT threads -> 1024 / NT elements each
-                constexpr int SPT = 1024 / NT;
-                const int srow = (tid * SPT) >> 4, scol = (tid * SPT) & 15;
+                // staging: 64 x CI_KC doubles per chunk, NT threads -> 64 CI_KC / NT elements each
+                constexpr int SPT = 64 * CI_KC / NT;
+                const int srow = (tid * SPT) / CI_KC, scol = (tid * SPT) % CI_KC;
                 const double *Bsrc = Lb + (size_t)(c0 + srow) * ld + scol;
                 double bnext[SPT];
 #pragma unroll
@@ -277,13 +277,17 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 __syncthreads();
                 for (int c = 0; c < nch; c++) {
                     const int buf = c & 1;
-                    // NO-PREFETCH experiment: operand loads for chunk c+1 are issued AFTER this chunk's MFMA block (below)
-                    v2d hc[UPW][2];
+                    // The history operand of chunk c is loaded here and consumed right below: NO software prefetch.
+                    // Measured: hipcc turns every use of a prefetched register into `s_waitcnt vmcnt(0)` (13 per
+                    // iteration), so a register prefetch ring hid nothing and its 32-64 extra VGPRs pushed two
+                    // accumulator tiles into scratch inside this loop (2.43 ms); without it the loop is spill
+                    // free and the second workgroup on the CU covers the load latency (2.28 ms, 512 x N=512).
+                    v2d hc[UPW][CI_KC / 8];
                     if (active && c >= cfirst) {
 #pragma unroll
                         for (int u = 0; u < UPW; u++)
 #pragma unroll
-                            for (int h = 0; h < 2; h++)
+                            for (int h = 0; h < CI_KC / 8; h++)
                                 hc[u][h] = *(const v2d *)(Hist + (size_t)(row0 + 16 * u + li) * ld + c * CI_KC + 8 * h + 2 * g);
                     }
                     if (c + 1 < nch) {
@@ -292,7 +296,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     }
                     if (active && c >= cfirst) {
 #pragma unroll
-                        for (int h = 0; h < 2; h++) {
+                        for (int h = 0; h < CI_KC / 8; h++) {
 #pragma unroll
                             for (int ct = 0; ct < 4; ct++) {
                                 const v2d a = *(const v2d *)&sm.Bs[buf][16 * ct + li][8 * h + 2 * g];
