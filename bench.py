@@ -49,6 +49,23 @@ def alg_work(kernel, N, Q, D, H):
     return table.get(kernel, (0.0, 0.0, "hbm"))
 
 
+def pmc_traffic(kernel, P, N):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json:
+    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; bytes = counter x 1024, FETCH_SIZE doubled
+    for 16-byte-per-lane streams as MI355X_MICROARCH.md's HBM section prescribes).  PMC and kernel-trace cannot be
+    combined in one run, so the value is measured offline and only returned for the shape it was measured on."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+    except (OSError, ValueError):
+        return None
+    if (P, N) != (512, 512):
+        return None
+    for name, v in d.items():
+        if name.split("<")[0] == kernel and "derived" in v:
+            return v["derived"]["fetch_bytes_x2_if_wide_loads"] + v["derived"]["write_bytes"]
+    return None
+
+
 def aggregate_time(t_local, world):
     """max over ranks of the local wall time (the driver's contract)."""
     if world <= 1:
@@ -225,7 +242,7 @@ def main():
         else:
             achieved = byts * P / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
-        roof.update({"traffic": None, "kernel": dom, "avg_launch_ms": avg_ms,
+        roof.update({"traffic": pmc_traffic(dom, P, N), "kernel": dom, "avg_launch_ms": avg_ms,
                      "alg_per_patient": {"flop": flop, "bytes": byts},
                      "kernel_ms_per_step": {k: round(v[0] / max(args.steps, 1), 4) for k, v in prof.items() if v[1] > 0}})
         f_alg = N ** 3 + 6 * N * N + 80 * Q * N * (N + 1) / 2
