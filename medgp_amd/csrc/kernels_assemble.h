@@ -31,6 +31,14 @@ __device__ __forceinline__ double exp_neg(double x) {
     return ldexp(p, n);
 }
 
+// value of `v` in lane `srclane` (wave-uniform index) as a scalar: two v_readlane_b32
+__device__ __forceinline__ double lane_bcast(double v, int srclane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, srclane);
+    hi = __builtin_amdgcn_readlane(hi, srclane);
+    return __hiloint2double(hi, lo);
+}
+
 template <int QT>
 __global__ void __launch_bounds__(256) k_assemble_t(MedgpDev L) {
     const int b = blockIdx.y;
@@ -58,17 +66,36 @@ __global__ void __launch_bounds__(256) k_assemble_t(MedgpDev L) {
     double csj[QT], snj[QT];
 #pragma unroll
     for (int q = 0; q < QT; q++) { csj[q] = csb[q * ld + j]; snj[q] = snb[q * ld + j]; }
+    // B_q[m_i][m_j]: observations are grouped by output, so m_i changes every ~N/D rows; the Q gathered values are kept
+    // in registers and re-gathered only when the (wave-uniform) row output changes -- 80 -> ~10 gathers per lane and
+    // tile (the per-element gathers kept the texture-address unit as busy as the VALU).
+    double bq[QT];
+    int mcur = -1;
+    // row constants of the wave's 16 rows: loaded once, lane r holds row r (lanes >= 16 mirror), broadcast per row with
+    // v_readlane -- instead of 2 + 2Q dependent scalar loads (and their lgkmcnt(0) stall) in every row iteration
+    const int irow = 64 * I + 16 * w + (lane & 15);
+    const double r_t = t[irow];
+    const int r_m = meta[irow];
+    double r_cs[QT], r_sn[QT];
+#pragma unroll
+    for (int q = 0; q < QT; q++) { r_cs[q] = csb[q * ld + irow]; r_sn[q] = snb[q * ld + irow]; }
     for (int rr = 0; rr < 16; rr++) {
         const int i = 64 * I + 16 * w + rr;          // wave-uniform
         double v;
         if (i < n) {
-            const double dt = t[i] - tj, dd = dt * dt;
-            const double *Brow = B + meta[i] * D + mj;
+            const int mi = __builtin_amdgcn_readlane(r_m, rr);
+            if (mi != mcur) {
+                mcur = mi;
+                const double *Brow = B + mi * D + mj;
+#pragma unroll
+                for (int q = 0; q < QT; q++) bq[q] = Brow[q * D * D];
+            }
+            const double dt = lane_bcast(r_t, rr) - tj, dd = dt * dt;
             double acc = 0.0;
 #pragma unroll
             for (int q = 0; q < QT; q++) {
-                const double cd = csb[q * ld + i] * csj[q] + snb[q * ld + i] * snj[q];
-                acc += Brow[q * D * D] * (cd * exp_neg(cq[q] * dd));
+                const double cd = lane_bcast(r_cs[q], rr) * csj[q] + lane_bcast(r_sn[q], rr) * snj[q];
+                acc += bq[q] * (cd * exp_neg(cq[q] * dd));
             }
             if (i == j) { const double lik = hyp[mj]; acc += lik; for (int r = 0; r < L.jit[b]; r++) acc += lik; }   // ref c_inference_exact.cpp:88-92, :101-104
             v = jv ? acc : 0.0;

@@ -135,10 +135,18 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
     for (int q = 0; q < QT; q++) { sS[q] = 0.0; sM[q] = 0.0; sV[q] = 0.0; }
     double *fl = Fl[w];
     int mcur = -2;
+    // row constants of the wave's 16 rows: loaded once (lane r holds row r, lanes >= 16 mirror) and broadcast per row
+    // with v_readlane, instead of 3 + 2Q dependent scalar loads per row iteration
+    const int irow = 64 * I + 16 * w + (lane & 15);
+    const double r_t = t[irow], r_a = alpha[irow];
+    const int r_m = (irow < n) ? meta[irow] : -1;
+    double r_cs[QT], r_sn[QT];
+#pragma unroll
+    for (int q = 0; q < QT; q++) { r_cs[q] = csb[q * ld + irow]; r_sn[q] = snb[q * ld + irow]; }
     for (int rr = 0; rr <= 16; rr++) {
         const int i = 64 * I + 16 * w + rr;
         int mi = -1;
-        if (rr < 16 && i < n) mi = meta[i];          // wave-uniform
+        if (rr < 16) mi = __builtin_amdgcn_readlane(r_m, rr);          // wave-uniform
         if (mi != mcur) {
             // flush the running sums of row output mcur (skip padding / initial state)
             if (mcur >= 0) {
@@ -162,7 +170,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
             mcur = mi;
         }
         if (rr == 16 || mi < 0) continue;
-        const double ti = t[i], ai = alpha[i];
+        const double ti = lane_bcast(r_t, rr), ai = lane_bcast(r_a, rr);
         double wv = Ws[16 * w + rr][lane] - ai * aj;
         if (I == J && j == i) L.wdiag[(size_t)b * ld + i] = wv;   // noise gradient needs diag(W)
         const bool valid = jv && (j <= i);
@@ -172,7 +180,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
         // (-w_q, -2 c_q) are applied once per flush -- 3 VALU less per (pair, component)
 #pragma unroll
         for (int q = 0; q < QT; q++) {
-            const double ci = csb[q * ld + i], si = snb[q * ld + i];   // wave-uniform loads
+            const double ci = lane_bcast(r_cs[q], rr), si = lane_bcast(r_sn[q], rr);
             const double we = wv * exp_neg(cq[q] * dd);
             const double cd = ci * csj[q] + si * snj[q];
             const double sd = si * csj[q] - ci * snj[q];
