@@ -28,7 +28,6 @@ template <int QT>
 __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
     // staging buffers (phase 1) and the W tile (phase 2/3) share storage
     __shared__ __attribute__((aligned(16))) double smem[2 * 64 * (WG_KC + 2)];
-    __shared__ double Fl[4][64];
     typedef double (*BsT)[64][WG_KC + 2];
     BsT Bs = (BsT)smem;                       // Bs[2][64][34]
     double (*Ws)[66] = (double (*)[66])smem;   // Ws[64][66]  (4224 <= 4352 doubles)
@@ -46,6 +45,13 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const double *U = L.Linv + (size_t)b * ld * ld;
 
+#ifdef MEDGP_STAMPS
+    unsigned long long wst[4] = {0, 0, 0, 0}, wlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wlast)::"memory");
+#define WSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); wst[k] += t_ - wlast; wlast = t_; } while (0)
+#else
+#define WSTAMP(k) do {} while (0)
+#endif
     // ---------------- phase 1: acc[ct] (rows 16w.. of block I, cols 16ct.. of block J)
     v4d acc[4];
 #pragma unroll
@@ -89,6 +95,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
             __syncthreads();
         }
     }
+    WSTAMP(0);
     // ---------------- phase 2: W tile -> LDS (all waves are past the last staging read: barrier above)
 #pragma unroll
     for (int ct = 0; ct < 4; ct++)
@@ -96,6 +103,7 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
         for (int r = 0; r < 4; r++) Ws[16 * w + 4 * r + g][16 * ct + li] = acc[ct][r];
     __syncthreads();
 
+    WSTAMP(1);
     // ---------------- phase 3
     const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
     const double *t = L.pt + (size_t)slot * ld;
@@ -127,13 +135,16 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
         unsigned long long above = (lane == 63) ? 0ull : (lmask >> (lane + 1));
         segend = above ? (lane + 1 + __builtin_ctzll(above)) : 64;
     }
+    // first lane of this lane's column segment, and whether this lane is its last one (it writes the segment sum)
+    const unsigned long long upto = lmask & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int segstart = 63 - __builtin_clzll(upto);
+    const bool seglast = (lane == segend - 1);
     const int cslot = (mj >= 0) ? coff[mj] + (J - seg[mj] / 64) : 0;
     const int rg = 4 * I + w;   // global 16-row group of this wave
 
     double sS[QT], sM[QT], sV[QT];
 #pragma unroll
     for (int q = 0; q < QT; q++) { sS[q] = 0.0; sM[q] = 0.0; sV[q] = 0.0; }
-    double *fl = Fl[w];
     int mcur = -2;
     // row constants of the wave's 16 rows: loaded once (lane r holds row r, lanes >= 16 mirror) and broadcast per row
     // with v_readlane, instead of 3 + 2Q dependent scalar loads per row iteration
@@ -155,14 +166,16 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
                 for (int pl = 0; pl < 3; pl++)
 #pragma unroll
                     for (int q = 0; q < QT; q++) {
-                        fl[lane] = (pl == 0) ? sS[q] : (pl == 1 ? -wq[q] * sM[q] : -2.0 * cq[q] * sV[q]);
-                        __builtin_amdgcn_wave_barrier();
-                        if (leader && mj >= 0) {
-                            double s = 0.0;
-                            for (int c2 = lane; c2 < segend; c2++) s += fl[c2];
-                            slab[((size_t)(pl * QT + q) * Rmax + rslot) * Cmax + cslot] = s;
+                        // segmented inclusive scan over the lanes (6 shuffle steps, fixed order): the last lane of
+                        // every column segment ends up with the segment sum.  (A serial per-segment loop here cost as
+                        // many VALU instructions as the whole pair loop.)
+                        double v = (pl == 0) ? sS[q] : (pl == 1 ? -wq[q] * sM[q] : -2.0 * cq[q] * sV[q]);
+#pragma unroll
+                        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                            const double up = __shfl_up(v, dlt);
+                            if (lane - dlt >= segstart) v += up;
                         }
-                        __builtin_amdgcn_wave_barrier();
+                        if (seglast && mj >= 0) slab[((size_t)(pl * QT + q) * Rmax + rslot) * Cmax + cslot] = v;
                     }
             }
 #pragma unroll
@@ -190,4 +203,12 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L) {
             sV[q] += p * dd;
         }
     }
+    WSTAMP(2);
+#ifdef MEDGP_STAMPS
+    if (lane == 0 && b < 64) {
+        unsigned long long *dbg = (unsigned long long *)(L.xk + (size_t)b * 64 * 64);
+        for (int e = 0; e < 3; e++) atomicAdd(&dbg[e], wst[e]);
+        atomicAdd(&dbg[3], 1ull);
+    }
+#endif
 }

@@ -685,6 +685,12 @@ int medgp_debug_read_slab(medgp_ctx *c, int b, void *out, int nbytes) {
     HIPCHK(c, hipMemcpy(out, c->dev.slab + (size_t)b * c->dev.slab_stride, nbytes, hipMemcpyDeviceToHost));
     return 0;
 }
+int medgp_debug_read_xk(medgp_ctx *c, int b, void *out, int nbytes, int clear) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->dev.xk + (size_t)b * 64 * 64, nbytes, hipMemcpyDeviceToHost));
+    if (clear) HIPCHK(c, hipMemset(c->dev.xk + (size_t)b * 64 * 64, 0, nbytes));
+    return 0;
+}
 #endif
 
 int medgp_profile_enable(medgp_ctx *c, int enable) {
