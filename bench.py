@@ -169,10 +169,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if ndev >= world:   # the driver's case: one rank per GPU, RCCL over xGMI
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:               # more ranks than GPUs (testing the multi-rank path on a 1-GPU box): share devices, gloo
+            local_rank = local_rank % max(ndev, 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
         local_rank = 0
