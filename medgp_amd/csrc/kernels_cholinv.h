@@ -110,7 +110,21 @@ __device__ inline bool diag16(double *T, double *X, double *rdl, int lane, doubl
         for (int j = 0; j < 16; j++) {
             double piv = readlane_d(a[j], j);
             if (!(piv > 0.0)) return false;
-            double sq = sqrt(piv), rinv = 1.0 / sq;
+            // sqrt and reciprocal sqrt together: v_rsq_f64 seed + two coupled Goldschmidt steps + one residual
+            // correction (about 1 ulp each; pivots of a scaled covariance never need the denormal rescaling that makes
+            // the library sqrt + divide a ~450-cycle dependent chain on this serial path)
+            double sq, rinv;
+            {
+                const double y0 = __builtin_amdgcn_rsq(piv);
+                double gg = piv * y0, hh = 0.5 * y0;
+                double rr = fma(-gg, hh, 0.5);
+                gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
+                rr = fma(-gg, hh, 0.5);
+                gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
+                const double dd = fma(-gg, gg, piv);
+                sq = fma(dd, hh, gg);
+                rinv = hh + hh;
+            }
             if (lane == j) rdl[j] = rinv;
             a[j] = (i == j) ? sq : a[j] * rinv;
 #pragma unroll
@@ -434,9 +448,239 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
     return true;
 }
 
+// ---- interleaved ownership ------------------------------------------------------------------------------------
+// Same recurrence, different split of a step's row blocks over the waves: a pass covers NW block slots (M blocks first,
+// then the U blocks by ascending row block) and wave w owns the 16-row unit (w & 3) of FOUR slots, so all waves carry
+// the same history profile (the U block of row block rho only has history from column 64 rho on): the per-chunk
+// barrier no longer makes short-history waves wait for long-history ones (75 % balance at N = 512 with whole-block
+// ownership), and chunks before the pass's first non-zero history column are skipped for the whole workgroup.
+// The active units of a wave at chunk c are a prefix of its slots, so the chunk body is instantiated per prefix length.
+#define CI_CHUNK_BODY(NA)                                                                                          \
+    {                                                                                                              \
+        v2d hc[NA][CI_KC / 8];                                                                                     \
+        _Pragma("unroll") for (int u = 0; u < NA; u++)                                                             \
+            _Pragma("unroll") for (int h = 0; h < CI_KC / 8; h++)                                                  \
+                hc[u][h] = *(const v2d *)(ub[u] + loff + c * CI_KC + 8 * h);                                       \
+        if (c + 1 < nch) {                                                                                         \
+            _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[(c + 1) * CI_KC + e];                  \
+        }                                                                                                          \
+        _Pragma("unroll") for (int h = 0; h < CI_KC / 8; h++) {                                                    \
+            _Pragma("unroll") for (int ct = 0; ct < 4; ct++) {                                                     \
+                const v2d a = *(const v2d *)&sm.Bs[buf][16 * ct + li][8 * h + 2 * g];                             \
+                _Pragma("unroll") for (int s = 0; s < 2; s++)                                                      \
+                    _Pragma("unroll") for (int u = 0; u < NA; u++)                                                 \
+                        acc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], hc[u][h][s], acc[ct][u], 0, 0, 0); \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+
+template <int NW>
+__device__ bool cholinv_attempt_il(const MedgpDev &L, int b, int slot, int n, int want_inv, CholInvSmem &sm) {
+    constexpr int NT = NW * 64;
+    constexpr int G = NW / 4;            // wave groups; a pass covers NW block slots
+    static_assert(NW % 4 == 0, "waves come in groups of four 16-row units");
+    const int ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
+    double *Lb = L.Kmat + (size_t)b * ld * ld;
+    double *Ub = L.Linv + (size_t)b * ld * ld;
+    double *zz = L.z + (size_t)b * ld;
+    double *alpha = L.alpha + (size_t)b * ld;
+    const double *y = L.py + (size_t)slot * ld;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int hwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = (b & 1) ? (NW - 1 - hwave) : hwave;   // mirrored on odd entries: the diagonal-factor waves of two
+                                                           // co-resident workgroups sit on different SIMDs
+    const int li = lane & 15, g = lane >> 4;
+    const int wu = wave & 3, wg = wave >> 2;
+    const int loff = li * ld + 2 * g;                      // lane part of an operand address
+
+    if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
+    __syncthreads();
+#ifdef MEDGP_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+
+    for (int k = 0; k < nb; k++) {
+        const int c0 = 64 * k;
+        const int nM = nb - k;
+        const int ntot = nM + (want_inv ? k : 0);
+        const int npass = (ntot + NW - 1) / NW;
+        const int nch = c0 / CI_KC;
+        for (int pass = 0; pass < npass; pass++) {
+            // my four slots (wave-uniform scalars)
+            bool act[4], isM[4];
+            int rowb[4], cf[4];
+            const double *ub[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int bidx = pass * NW + u * G + wg;
+                act[u] = bidx < ntot;
+                isM[u] = bidx < nM;
+                const int rblk = isM[u] ? (k + bidx) : (bidx - nM);
+                rowb[u] = 64 * rblk + 16 * wu;
+                cf[u] = act[u] ? (isM[u] ? 0 : (64 * rblk) / CI_KC) : (1 << 30);
+                ub[u] = (isM[u] ? Lb : Ub) + (size_t)rowb[u] * ld;
+            }
+            // first chunk anybody in the workgroup needs: slot 0 of group 0 has the longest history
+            const int bidx0 = pass * NW;
+            const int cstart = (bidx0 < nM) ? 0 : (64 * (bidx0 - nM)) / CI_KC;
+            v4d acc[4][4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
+                    if (act[u] && isM[u]) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[ct][u][r] = -Lb[(size_t)(rowb[u] + li) * ld + c0 + 16 * ct + 4 * r + g];
+                    }
+                }
+            STAMP(0);
+            double zsum = 0.0;
+            if (nch > cstart) {
+                constexpr int SPT = 64 * CI_KC / NT;
+                const int srow = (tid * SPT) / CI_KC, scol = (tid * SPT) % CI_KC;
+                const double *Bsrc = Lb + (size_t)(c0 + srow) * ld + scol;
+                double bnext[SPT];
+#pragma unroll
+                for (int e = 0; e < SPT; e++) { bnext[e] = Bsrc[cstart * CI_KC + e]; sm.Bs[cstart & 1][srow][scol + e] = bnext[e]; }
+                __syncthreads();
+                for (int c = cstart; c < nch; c++) {
+                    const int buf = c & 1;
+                    const int nact = (c >= cf[0]) + (c >= cf[1]) + (c >= cf[2]) + (c >= cf[3]);
+                    if (nact == 4) CI_CHUNK_BODY(4)
+                    else if (nact == 3) CI_CHUNK_BODY(3)
+                    else if (nact == 2) CI_CHUNK_BODY(2)
+                    else if (nact == 1) CI_CHUNK_BODY(1)
+                    else if (c + 1 < nch) {
+#pragma unroll
+                        for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[(c + 1) * CI_KC + e];
+                    }
+                    if (pass == 0 && wave == NW - 1) {
+                        if (npad <= 1024) {
+#pragma unroll
+                            for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * sm.zs[c * CI_KC + kk];
+                        } else {
+#pragma unroll
+                            for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * zz[c * CI_KC + kk];
+                        }
+                    }
+                    STAMP(4);
+                    if (c + 1 < nch) {
+#pragma unroll
+                        for (int e = 0; e < SPT; e++) sm.Bs[buf ^ 1][srow][scol + e] = bnext[e];
+                    }
+                    STAMP(6);
+                    __syncthreads();
+                    STAMP(7);
+                }
+            }
+            STAMP(1);
+            if (pass == 0) {
+                // diagonal block = slot 0 of group 0: every wave of the group holds 16 of its rows
+                if (wg == 0) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) sm.Dk[16 * wu + li][16 * ct + 4 * r + g] = -acc[ct][0][r];
+                }
+                if (wave == NW - 1) sm.zacc[lane] = zsum;
+                __syncthreads();
+                STAMP(0);
+                if (wave == 0) {
+                    diag_factor_wave(sm, lane);
+                    STAMP(3);
+                    if (!sm.fail) {
+                        sm.rhs[lane] = ((c0 + lane < n) ? y[c0 + lane] : 0.0) - sm.zacc[lane];
+                        __builtin_amdgcn_wave_barrier();
+                        // Xk is stored with exact zeros above the diagonal, so the fixed-length loops below add the same
+                        // terms in the same order as a triangular loop would, but pipeline their LDS reads
+                        double s = 0.0;
+#pragma unroll 16
+                        for (int cc = 0; cc < 64; cc++) s += sm.Xk[lane][cc] * sm.rhs[cc];
+                        zz[c0 + lane] = s;
+                        sm.zk[lane] = s;
+                        if (c0 + lane < 1024) sm.zs[c0 + lane] = s;
+                        if (want_inv) {
+                            __builtin_amdgcn_wave_barrier();
+                            double a0 = 0.0;
+#pragma unroll 16
+                            for (int cc = 0; cc < 64; cc++) a0 += sm.Xk[cc][lane] * sm.zk[cc];
+                            alpha[c0 + lane] = a0;
+                        }
+                    }
+                }
+                __syncthreads();
+                STAMP(2);   // z / alpha solves of wave 0, or waiting for the diagonal phase
+                if (sm.fail) return false;
+                for (int e = tid; e < 64 * 64; e += NT) {
+                    int rr = e >> 6, cc = e & 63;
+                    if (cc <= rr) Lb[(size_t)(c0 + rr) * ld + c0 + cc] = sm.Dk[rr][cc];
+                    if (want_inv) Ub[(size_t)(c0 + rr) * ld + c0 + cc] = (cc >= rr) ? sm.Xk[cc][rr] : 0.0;
+                }
+            }
+            STAMP(3);
+            // triangular solve as GEMM on all four units (an inactive or diagonal unit computes on zeros / unused
+            // values: 40 MFMAs, never stored), stores and alpha guarded per unit
+            {
+                bool st[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) st[u] = act[u] && !(pass == 0 && wg == 0 && u == 0);
+                double pal[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ct = 3; ct >= 0; ct--) {
+                    v4d o[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) o[u] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int cp = 0; cp <= ct; cp++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            double a = -sm.Xk[16 * ct + li][16 * cp + 4 * r + g];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) o[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[cp][u][r], o[u], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (st[u]) {
+                            double *Out = (isM[u] ? Lb : Ub) + (size_t)(rowb[u] + li) * ld + c0 + 16 * ct + g;
+#pragma unroll
+                            for (int r = 0; r < 4; r++) Out[4 * r] = o[u][r];
+                            if (!isM[u]) {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) pal[u] += o[u][r] * sm.zk[16 * ct + 4 * r + g];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (st[u] && !isM[u]) {
+                        double v = pal[u];
+                        v += __shfl_xor(v, 16);
+                        v += __shfl_xor(v, 32);
+                        if (g == 0) alpha[rowb[u] + li] += v;
+                    }
+                }
+            }
+            STAMP(5);
+            __syncthreads();
+            STAMP(5);
+        }
+    }
+#ifdef MEDGP_STAMPS
+    if (lane == 0 && b < 64) {
+        unsigned long long *dbg = (unsigned long long *)(L.slab + (size_t)b * L.slab_stride);
+        for (int e = 0; e < 8; e++) dbg[(tid >> 6) * 8 + e] = st_acc[e];
+    }
+#endif
+    return true;
+}
+
+
 // grid = nbatch, block = NW * 64.  NW = 16: one workgroup per CU (lowest latency per patient);
 // NW = 8: two workgroups per CU, the serial diagonal-block phase of one overlaps the MFMA phase of the other.
-template <int NW, int UPW>
+template <int NW, int UPW, bool IL = false>
 __global__ void __launch_bounds__(NW * 64, 2) k_cholinv(MedgpDev L, int want_inv) {
     constexpr int NT = NW * 64;
     __shared__ CholInvSmem sm;
@@ -445,7 +689,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_cholinv(MedgpDev L, int want_inv
     const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64);
     int count = 0;
     while (true) {
-        if (cholinv_attempt<NW, UPW>(L, b, slot, n, want_inv, sm)) break;
+        if (IL ? cholinv_attempt_il<NW>(L, b, slot, n, want_inv, sm) : cholinv_attempt<NW, UPW>(L, b, slot, n, want_inv, sm)) break;
         __syncthreads();
         if (count >= 10) {   // ref: c_inference_exact.cpp:99,109-111
             if (tid == 0) L.status[b] = -1;
