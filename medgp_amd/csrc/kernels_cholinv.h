@@ -21,6 +21,11 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
+// Explicit global-address-space views.  k_cholinv hands its by-value argument struct to noinline helpers by reference,
+// after which hipcc no longer proves that the pointers inside are global and emits FLAT loads / stores (which also
+// count on lgkmcnt, i.e. every LDS wait then waits for the HBM operands too).
+typedef __attribute__((address_space(1))) double gd_t;
+typedef __attribute__((address_space(1))) v2d gv2d_t;
 
 #define CI_KC 16          // k-columns staged per barrier (32 spills accumulators in the hot loop)
 
@@ -45,24 +50,34 @@ typedef double v2d __attribute__((ext_vector_type(2)));
         (void)t_;                                                                                  \
     } while (0)
 #endif
-#define CI_THREADS 1024   // largest workgroup (16 waves: 8 blocks x 2 halves per pass)
+#ifndef CI_SLAB_INIT
+#define CI_SLAB_INIT 0   // 1: init through the slab too (coalesced, but hipcc then spills accumulator tiles in the MFMA loop: 2.2 vs 1.8 ms)
+#endif
+#ifndef CI_SLAB_STORE
+#define CI_SLAB_STORE 1
+#endif
+#define CI_ST 18          // row stride (doubles) of a wave's transposition slab: 144 B keeps 16-byte alignment
 
+template <int NW>
 struct CholInvSmem {
-    union {                            // never live at the same time: Bs during the history GEMM, Dk afterwards
-        double Bs[2][64][CI_KC + 2];   // staged chunk of L[C_k rows][kc .. kc+16)
-        double Dk[64][66];             // diagonal block: in D, out L_kk (lower)
+    union {                            // never live at the same time (barriers in cholinv_attempt separate the uses)
+        double Bs[2][64][CI_KC + 2];   // history GEMM: staged chunk of L[C_k rows][kc .. kc+16)
+        double Dk[64][66];             // diagonal phase: in D, out L_kk (lower)
+        double St[NW][64][CI_ST];      // panel init / panel store: per-wave 64 x 16 slab that turns row-contiguous
+                                       // 16-byte global accesses into the transposed accumulator layout
     };
-    double Xk[64][66];             // L_kk^-1 (lower)
+    double Xk[64][66];             // L_kk^-1 (lower, exact zeros above the diagonal)
     double zacc[64];               // L[C_k, 0:64k] z[0:64k]
     double rhs[64];
     double zk[64];                 // z of the current panel (for the in-step alpha accumulation)
     double zs[1024];               // z history kept in LDS for n <= 1024: the in-loop z product then issues no
-                                   // global loads, whose wait (vmcnt) would also drain the operand prefetch
+                                   // global loads, whose wait (vmcnt) would also drain the operand loads
     double rdiag[16];              // 1 / diag of the current 16x16 tile
     double red[16];
     double logdet;
     int fail;
 };
+static_assert(sizeof(CholInvSmem<4>) <= 80 * 1024, "two 4-wave workgroups per CU need <= 80 KB each");
 
 #define CI_S 66   // LDS row stride (doubles) of Dk / Xk
 
@@ -165,16 +180,16 @@ __device__ inline bool diag16(double *T, double *X, double *rdl, int lane, doubl
 
 // Cholesky of the 64x64 block in sm.Dk (lower, in place) and its inverse into sm.Xk (lower), on ONE wave:
 // 16x16 tiles, diagonal tiles in registers (diag16), everything else as MFMA tile products out of LDS.
-__device__ __attribute__((noinline)) void diag_factor_wave(CholInvSmem &sm, int lane) {
+// D, X: 64 x 64 with row stride CI_S; rdiag: 16 doubles of scratch; *fail is set on a bad pivot; *logdet += sum log diag.
+__device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X, double *rdiag, int *fail, double *logdet, int lane) {
     const int li = lane & 15, g = lane >> 4;
-    double *D = &sm.Dk[0][0], *X = &sm.Xk[0][0];
 #define TD(s, t) (D + (16 * (s)) * CI_S + 16 * (t))
 #define TX(s, t) (X + (16 * (s)) * CI_S + 16 * (t))
     double logsum = 0.0;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
     for (int t = 0; t < 4; t++) {
-        if (!diag16(TD(t, t), TX(t, t), sm.rdiag, lane, &logsum)) { if (lane == 0) sm.fail = 1; return; }
+        if (!diag16(TD(t, t), TX(t, t), rdiag, lane, &logsum)) { if (lane == 0) *fail = 1; return; }
         __builtin_amdgcn_wave_barrier();
         // panel below: L(s,t) = D(s,t) X(t,t)^T
 #pragma unroll 1
@@ -214,33 +229,98 @@ __device__ __attribute__((noinline)) void diag_factor_wave(CholInvSmem &sm, int 
 #pragma unroll 1
     for (int t = 1; t < 4; t++)
         for (int s2 = 0; s2 < t; s2++) tile_st(TX(s2, t), zero4, li, g);
-    if (lane == 0) sm.logdet += logsum;
+    if (lane == 0) *logdet += logsum;
 #undef TD
 #undef TX
 }
 
-// one factorisation attempt; returns false if a pivot failed
-template <int NW, int UPW>
-__device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int want_inv, CholInvSmem &sm) {
-    constexpr int NT = NW * 64;          // threads
-    constexpr int RPW = 16 * UPW;        // rows per wave (UPW 16-row MFMA units)
-    constexpr int WPB = 64 / RPW;        // waves per 64-row block
-    constexpr int BP = NW / WPB;         // 64-row blocks per pass
-    static_assert(WPB == 1, "one wave owns a whole 64-row block");
+// ---- one factorisation attempt; returns false if a pivot failed ---------------------------------------------------
+// Split of a step's row blocks over the waves: a pass covers NW block slots (M blocks first, then the U blocks by
+// ascending row block) and wave w owns the 16-row unit (w & 3) of FOUR slots, so all waves carry the same history
+// profile (the U block of row block rho only has history from column 64 rho on): the per-chunk barrier never makes a
+// short-history wave wait for a long-history one (whole-block ownership: 75 % balance at N = 512), and chunks before the
+// pass's first non-zero history column are skipped for the whole workgroup.  The active units of a wave at chunk c
+// are a prefix of its slots, so the chunk body is instantiated per prefix length.
+// Diagnostic build only (-DCI_EXP_ALIAS=n): history operands are read from batch entry b % n and scaled by zero, so the
+// kernel keeps its instruction stream but its history traffic becomes cache resident (results are wrong by design).
+#ifdef CI_EXP_ALIAS
+#define CI_EXP_OFF exp_off
+#define CI_EXP_SCALE(x) ((x) * exp_zero)
+#else
+#define CI_EXP_OFF 0
+#define CI_EXP_SCALE(x) (x)
+#endif
+// One phase of the chunk loop: chunks [lo, hi) during which exactly the first NA units of this wave are active.
+#define CI_CHUNK_PHASE(NA, lo, hi)                                                                                 \
+    for (int c = (lo); c < (hi); c++) {                                                                            \
+        const int buf = c & 1;                                                                                     \
+        v2d hc[NA > 0 ? NA : 1][CI_KC / 8];                                                                        \
+        _Pragma("unroll") for (int u = 0; u < NA; u++)                                                             \
+            _Pragma("unroll") for (int h = 0; h < CI_KC / 8; h++)                                                  \
+                hc[u][h] = CI_EXP_SCALE(*(const gv2d_t *)(ub[u] + CI_EXP_OFF + loff + c * CI_KC + 8 * h));         \
+        if (c + 1 < nch) {                                                                                         \
+            _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = CI_EXP_SCALE(Bsrc[CI_EXP_OFF + (c + 1) * CI_KC + e]); \
+        }                                                                                                          \
+        if (NA > 0) {                                                                                              \
+            _Pragma("unroll") for (int h = 0; h < CI_KC / 8; h++) {                                                \
+                _Pragma("unroll") for (int ct = 0; ct < 4; ct++) {                                                 \
+                    const v2d a = *(const v2d *)&sm.Bs[buf][16 * ct + li][8 * h + 2 * g];                         \
+                    _Pragma("unroll") for (int s = 0; s < 2; s++)                                                  \
+                        _Pragma("unroll") for (int u = 0; u < NA; u++)                                             \
+                            acc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], hc[u][h][s], acc[ct][u], 0, 0, 0); \
+                }                                                                                                  \
+            }                                                                                                      \
+        }                                                                                                          \
+        /* z history product (pass 0 only): last wave, lane = panel column */                                      \
+        if (pass == 0 && wave == NW - 1) {                                                                         \
+            if (npad <= 1024) {                                                                                    \
+                _Pragma("unroll") for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * sm.zs[c * CI_KC + kk]; \
+            } else {                                                                                               \
+                _Pragma("unroll") for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * zz[c * CI_KC + kk];    \
+            }                                                                                                      \
+        }                                                                                                          \
+        STAMP(4); /* MFMA block (+ z product) */                                                                   \
+        if (c + 1 < nch) {                                                                                         \
+            _Pragma("unroll") for (int e = 0; e < SPT; e++) sm.Bs[buf ^ 1][srow][scol + e] = bnext[e];             \
+        }                                                                                                          \
+        STAMP(6); /* staging store (waits for this iteration's B loads) */                                         \
+        __syncthreads();                                                                                           \
+        STAMP(7); /* chunk barrier wait */                                                                         \
+    }
+
+template <int NW>
+__device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int want_inv, CholInvSmem<NW> &sm) {
+    constexpr int NT = NW * 64;
+    constexpr int G = NW / 4;            // wave groups; a pass covers NW block slots
+    static_assert(NW % 4 == 0, "waves come in groups of four 16-row units");
     const int ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
-    double *Lb = L.Kmat + (size_t)b * ld * ld;
-    double *Ub = L.Linv + (size_t)b * ld * ld;
-    double *zz = L.z + (size_t)b * ld;
-    double *alpha = L.alpha + (size_t)b * ld;
-    const double *y = L.py + (size_t)slot * ld;
-    // virtual wave id: odd batch entries mirror the wave order, so that when two workgroups share a CU the
-    // heavy waves (diagonal owner, longest histories) of one sit beside the light waves of the other
+    gd_t *Lb = (gd_t *)(L.Kmat + (size_t)b * ld * ld);
+    gd_t *Ub = (gd_t *)(L.Linv + (size_t)b * ld * ld);
+    gd_t *zz = (gd_t *)(L.z + (size_t)b * ld);
+    gd_t *alpha = (gd_t *)(L.alpha + (size_t)b * ld);
+    const gd_t *y = (const gd_t *)(L.py + (size_t)slot * ld);
     const int tid = threadIdx.x, lane = tid & 63;
     const int hwave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> scalar control flow + scalar bases
-    const int wave = (b & 1) ? (NW - 1 - hwave) : hwave;
+    const int wave = (b & 1) ? (NW - 1 - hwave) : hwave;   // mirrored on odd entries: the diagonal-factor waves of two
+                                                           // co-resident workgroups sit on different SIMDs
     const int li = lane & 15, g = lane >> 4;
-    const int wblk = wave / WPB, wsub = wave % WPB;
+    const int wu = wave & 3, wg = wave >> 2;
+    const int loff = li * ld + 2 * g;                      // lane part of a history-operand address
+    // row-contiguous access of a 64 x 16 column slab: one instruction = 8 rows x 128 B (whole cache lines); the 8-byte
+    // accesses of the transposed accumulator layout touch 64 lines per instruction and made panel init + panel store
+    // tag-lookup bound in the L1 (a fifth of the kernel).  The slab is transposed through LDS instead.
+    // (its lane constants are re-derived from an opaque copy of the lane id at each use: hoisted out of the pass loop
+    //  they would stay live across the MFMA loop and push accumulator tiles into scratch)
+#define CI_SLAB_LANE()                                   \
+    int lane_o = lane;                                   \
+    asm volatile("" : "+v"(lane_o));                     \
+    const int srow8 = lane_o >> 3, spc = lane_o & 7;     \
+    double (*S)[CI_ST] = sm.St[hwave]
 
+#ifdef CI_EXP_ALIAS
+    const long exp_off = ((long)(b % CI_EXP_ALIAS) - (long)b) * ld * ld;
+    const double exp_zero = (L.ldn < 0) ? 1.0 : 0.0;   // opaque zero
+#endif
     if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
     __syncthreads();
 #ifdef MEDGP_STAMPS
@@ -252,265 +332,13 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
         const int c0 = 64 * k;                       // first column of the panel
         const int nM = nb - k;                       // K-row blocks (first one is the diagonal block)
         const int ntot = nM + (want_inv ? k : 0);    // + U-row blocks
-        const int npass = (ntot + BP - 1) / BP;
-        const int nch = c0 / CI_KC;                  // history chunks
-        for (int pass = 0; pass < npass; pass++) {
-            // odd passes walk the block list backwards: pairs long histories with short ones per wave
-            const int bidx = pass * BP + ((pass & 1) ? (BP - 1 - wblk) : wblk);
-            const bool active = bidx < ntot;
-            const bool isM = bidx < nM;
-            const int rblk = isM ? (k + bidx) : (bidx - nM);           // row block of this wave
-            const int row0 = 64 * rblk + RPW * wsub;                   // first of my RPW rows
-            const double *Hist = isM ? Lb : Ub;
-            const int kstart = isM ? 0 : 64 * rblk;
-            const int cfirst = kstart / CI_KC;
-            // acc starts at -init (init = K block for K rows, 0 for U rows); the history GEMM adds P, so the
-            // panel value is  init - P = -acc  (the sign is folded into the operands that consume acc)
-            v4d acc[4][UPW];
-#pragma unroll
-            for (int ct = 0; ct < 4; ct++)
-#pragma unroll
-                for (int u = 0; u < UPW; u++) {
-                    acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
-                    if (active && isM) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) acc[ct][u][r] = -Lb[(size_t)(row0 + 16 * u + li) * ld + c0 + 16 * ct + 4 * r + g];
-                    }
-                }
-            STAMP(0);   // init loads issued
-            double zsum = 0.0;
-            // ---- GEMM over the history, B chunk (L[C_k rows]) staged through LDS, double buffered
-            if (nch > 0) {
-                // staging: 64 x CI_KC doubles per chunk, NT threads -> 64 CI_KC / NT elements each
-                constexpr int SPT = 64 * CI_KC / NT;
-                const int srow = (tid * SPT) / CI_KC, scol = (tid * SPT) % CI_KC;
-                const double *Bsrc = Lb + (size_t)(c0 + srow) * ld + scol;
-                double bnext[SPT];
-#pragma unroll
-                for (int e = 0; e < SPT; e++) { bnext[e] = Bsrc[e]; sm.Bs[0][srow][scol + e] = bnext[e]; }
-                __syncthreads();
-                for (int c = 0; c < nch; c++) {
-                    const int buf = c & 1;
-                    // The history operand of chunk c is loaded here and consumed right below: NO software prefetch.
-                    // Measured: hipcc turns every use of a prefetched register into `s_waitcnt vmcnt(0)` (13 per
-                    // iteration), so a register prefetch ring hid nothing and its 32-64 extra VGPRs pushed two
-                    // accumulator tiles into scratch inside this loop (2.43 ms); without it the loop is spill
-                    // free and the second workgroup on the CU covers the load latency (2.28 ms, 512 x N=512).
-                    v2d hc[UPW][CI_KC / 8];
-                    if (active && c >= cfirst) {
-#pragma unroll
-                        for (int u = 0; u < UPW; u++)
-#pragma unroll
-                            for (int h = 0; h < CI_KC / 8; h++)
-                                hc[u][h] = *(const v2d *)(Hist + (size_t)(row0 + 16 * u + li) * ld + c * CI_KC + 8 * h + 2 * g);
-                    }
-                    if (c + 1 < nch) {
-#pragma unroll
-                        for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[(c + 1) * CI_KC + e];
-                    }
-                    if (active && c >= cfirst) {
-#pragma unroll
-                        for (int h = 0; h < CI_KC / 8; h++) {
-#pragma unroll
-                            for (int ct = 0; ct < 4; ct++) {
-                                const v2d a = *(const v2d *)&sm.Bs[buf][16 * ct + li][8 * h + 2 * g];
-#pragma unroll
-                                for (int s = 0; s < 2; s++)
-#pragma unroll
-                                    for (int u = 0; u < UPW; u++)
-                                        acc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], hc[u][h][s], acc[ct][u], 0, 0, 0);
-                            }
-                        }
-                    }
-                    // z history product (pass 0 only): wave 15, lane = panel column
-                    if (pass == 0 && wave == NW - 1) {
-                        if (npad <= 1024) {
-#pragma unroll
-                            for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * sm.zs[c * CI_KC + kk];
-                        } else {
-#pragma unroll
-                            for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * zz[c * CI_KC + kk];
-                        }
-                    }
-                    STAMP(4);   // MFMA block (+ z product)
-                    if (c + 1 < nch) {
-#pragma unroll
-                        for (int e = 0; e < SPT; e++) sm.Bs[buf ^ 1][srow][scol + e] = bnext[e];
-                    }
-                    STAMP(6);   // staging store (waits for this iteration's B loads)
-                    __syncthreads();
-                    STAMP(7);   // chunk barrier wait
-                }
-            }
-            STAMP(1);   // history GEMM (incl. chunk barriers)
-            if (pass == 0) {
-                // diagonal block (block index 0 = waves 0,1) -> LDS, factor, invert
-                if (wblk == 0) {
-#pragma unroll
-                    for (int ct = 0; ct < 4; ct++)
-#pragma unroll
-                        for (int u = 0; u < UPW; u++)
-#pragma unroll
-                            for (int r = 0; r < 4; r++) sm.Dk[RPW * wsub + 16 * u + li][16 * ct + 4 * r + g] = -acc[ct][u][r];
-                }
-                if (wave == NW - 1) sm.zacc[lane] = zsum;
-                __syncthreads();
-                STAMP(0);   // wait for the slowest GEMM wave (folded into 0)
-                if (wave == 0) {
-                    diag_factor_wave(sm, lane);
-                    if (!sm.fail) {
-                        // z_k = L_kk^-1 (y_k - zacc)
-                        sm.rhs[lane] = ((c0 + lane < n) ? y[c0 + lane] : 0.0) - sm.zacc[lane];
-                        __builtin_amdgcn_wave_barrier();
-                        double s = 0.0;
-                        for (int cc = 0; cc <= lane; cc++) s += sm.Xk[lane][cc] * sm.rhs[cc];
-                        zz[c0 + lane] = s;
-                        sm.zk[lane] = s;
-                        if (c0 + lane < 1024) sm.zs[c0 + lane] = s;
-                        if (want_inv) {
-                            // alpha = U z accumulated panel by panel; the diagonal block U_kk = L_kk^-T opens rows C_k
-                            __builtin_amdgcn_wave_barrier();
-                            double a0 = 0.0;
-                            for (int cc = lane; cc < 64; cc++) a0 += sm.Xk[cc][lane] * sm.zk[cc];
-                            alpha[c0 + lane] = a0;
-                        }
-                    }
-                }
-                __syncthreads();
-                STAMP(3);   // diagonal factor (wave 0) / waiting for it
-                if (sm.fail) return false;
-                // store L_kk (lower) and U_kk = L_kk^-T (upper, zeros below)
-                for (int e = tid; e < 64 * 64; e += NT) {
-                    int rr = e >> 6, cc = e & 63;
-                    if (cc <= rr) Lb[(size_t)(c0 + rr) * ld + c0 + cc] = sm.Dk[rr][cc];
-                    if (want_inv) Ub[(size_t)(c0 + rr) * ld + c0 + cc] = (cc >= rr) ? sm.Xk[cc][rr] : 0.0;
-                }
-            }
-            // ---- panel solve  L_kk out^T = val^T (val = -acc) by 16x16 tile substitution, in place in acc:
-            //        t = acc[ct] + sum_{cp<ct} L(ct,cp) out[cp];   out[ct] = (-X(ct,ct)) t
-            // The diagonal-block owner (pass 0, block 0) solves for the identity instead: its rows of the panel
-            // are U_kk = L_kk^-T, the diagonal block of the inverse factor.
-            STAMP(3);   // L_kk / U_kk stores (folded into diag)
-            // ---- triangular solve as GEMM: out^T[ct] = sum_{ct' <= ct} (-Xk[ct, ct']) acc^T[ct'], then store
-            //      (measured faster than substituting tile by tile: four independent accumulator chains per unit)
-            if (active && !(pass == 0 && wblk == 0)) {
-                double *Out = isM ? Lb : Ub;
-                double pal[UPW];
-#pragma unroll
-                for (int u = 0; u < UPW; u++) pal[u] = 0.0;
-#pragma unroll
-                for (int ct = 3; ct >= 0; ct--) {
-                    v4d o[UPW];
-#pragma unroll
-                    for (int u = 0; u < UPW; u++) o[u] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int cp = 0; cp <= ct; cp++)
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            double a = -sm.Xk[16 * ct + li][16 * cp + 4 * r + g];
-#pragma unroll
-                            for (int u = 0; u < UPW; u++) o[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[cp][u][r], o[u], 0, 0, 0);
-                        }
-#pragma unroll
-                    for (int u = 0; u < UPW; u++)
-#pragma unroll
-                        for (int r = 0; r < 4; r++) Out[(size_t)(row0 + 16 * u + li) * ld + c0 + 16 * ct + 4 * r + g] = o[u][r];
-                    if (!isM) {   // U rows: alpha_i += sum_c U[i][c] z_k[c]
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const double zc = sm.zk[16 * ct + 4 * r + g];
-#pragma unroll
-                            for (int u = 0; u < UPW; u++) pal[u] += o[u][r] * zc;
-                        }
-                    }
-                }
-                if (!isM) {
-#pragma unroll
-                    for (int u = 0; u < UPW; u++) {
-                        double v = pal[u];
-                        v += __shfl_xor(v, 16);
-                        v += __shfl_xor(v, 32);
-                        if (g == 0) alpha[row0 + 16 * u + li] += v;   // this wave owns these rows in this step
-                    }
-                }
-            }
-            STAMP(5);   // panel solve + stores
-            __syncthreads();   // stores of this step visible to the whole workgroup before the next history read
-            STAMP(5);   // end-of-step barrier (folded into trsm)
-        }
-    }
-#ifdef MEDGP_STAMPS
-    if (lane == 0 && b < 64) {
-        unsigned long long *dbg = (unsigned long long *)(L.slab + (size_t)b * L.slab_stride);
-        for (int e = 0; e < 8; e++) dbg[(tid >> 6) * 8 + e] = st_acc[e];
-    }
-#endif
-    return true;
-}
-
-// ---- interleaved ownership ------------------------------------------------------------------------------------
-// Same recurrence, different split of a step's row blocks over the waves: a pass covers NW block slots (M blocks first,
-// then the U blocks by ascending row block) and wave w owns the 16-row unit (w & 3) of FOUR slots, so all waves carry
-// the same history profile (the U block of row block rho only has history from column 64 rho on): the per-chunk
-// barrier no longer makes short-history waves wait for long-history ones (75 % balance at N = 512 with whole-block
-// ownership), and chunks before the pass's first non-zero history column are skipped for the whole workgroup.
-// The active units of a wave at chunk c are a prefix of its slots, so the chunk body is instantiated per prefix length.
-#define CI_CHUNK_BODY(NA)                                                                                          \
-    {                                                                                                              \
-        v2d hc[NA][CI_KC / 8];                                                                                     \
-        _Pragma("unroll") for (int u = 0; u < NA; u++)                                                             \
-            _Pragma("unroll") for (int h = 0; h < CI_KC / 8; h++)                                                  \
-                hc[u][h] = *(const v2d *)(ub[u] + loff + c * CI_KC + 8 * h);                                       \
-        if (c + 1 < nch) {                                                                                         \
-            _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[(c + 1) * CI_KC + e];                  \
-        }                                                                                                          \
-        _Pragma("unroll") for (int h = 0; h < CI_KC / 8; h++) {                                                    \
-            _Pragma("unroll") for (int ct = 0; ct < 4; ct++) {                                                     \
-                const v2d a = *(const v2d *)&sm.Bs[buf][16 * ct + li][8 * h + 2 * g];                             \
-                _Pragma("unroll") for (int s = 0; s < 2; s++)                                                      \
-                    _Pragma("unroll") for (int u = 0; u < NA; u++)                                                 \
-                        acc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], hc[u][h][s], acc[ct][u], 0, 0, 0); \
-            }                                                                                                      \
-        }                                                                                                          \
-    }
-
-template <int NW>
-__device__ bool cholinv_attempt_il(const MedgpDev &L, int b, int slot, int n, int want_inv, CholInvSmem &sm) {
-    constexpr int NT = NW * 64;
-    constexpr int G = NW / 4;            // wave groups; a pass covers NW block slots
-    static_assert(NW % 4 == 0, "waves come in groups of four 16-row units");
-    const int ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
-    double *Lb = L.Kmat + (size_t)b * ld * ld;
-    double *Ub = L.Linv + (size_t)b * ld * ld;
-    double *zz = L.z + (size_t)b * ld;
-    double *alpha = L.alpha + (size_t)b * ld;
-    const double *y = L.py + (size_t)slot * ld;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int hwave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = (b & 1) ? (NW - 1 - hwave) : hwave;   // mirrored on odd entries: the diagonal-factor waves of two
-                                                           // co-resident workgroups sit on different SIMDs
-    const int li = lane & 15, g = lane >> 4;
-    const int wu = wave & 3, wg = wave >> 2;
-    const int loff = li * ld + 2 * g;                      // lane part of an operand address
-
-    if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
-    __syncthreads();
-#ifdef MEDGP_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
-#endif
-
-    for (int k = 0; k < nb; k++) {
-        const int c0 = 64 * k;
-        const int nM = nb - k;
-        const int ntot = nM + (want_inv ? k : 0);
         const int npass = (ntot + NW - 1) / NW;
-        const int nch = c0 / CI_KC;
+        const int nch = c0 / CI_KC;                  // history chunks
         for (int pass = 0; pass < npass; pass++) {
             // my four slots (wave-uniform scalars)
             bool act[4], isM[4];
             int rowb[4], cf[4];
-            const double *ub[4];
+            const gd_t *ub[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int bidx = pass * NW + u * G + wg;
@@ -524,6 +352,55 @@ __device__ bool cholinv_attempt_il(const MedgpDev &L, int b, int slot, int n, in
             // first chunk anybody in the workgroup needs: slot 0 of group 0 has the longest history
             const int bidx0 = pass * NW;
             const int cstart = (bidx0 < nM) ? 0 : (64 * (bidx0 - nM)) / CI_KC;
+            // acc starts at -init (init = K block for K rows, 0 for U rows); the history GEMM adds P, so the panel
+            // value is  init - P = -acc  (the sign is folded into the operands that consume acc)
+#if CI_SLAB_INIT
+            v4d acc[4][4];
+            {
+                CI_SLAB_LANE();
+                bool ldu[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) ldu[u] = act[u] && isM[u];
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    v2d kin[2][8];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (ldu[u]) {
+                            const gd_t *src = ub[u] + (size_t)srow8 * ld + c0 + 32 * half + 2 * spc;
+#pragma unroll
+                            for (int cth = 0; cth < 2; cth++)
+#pragma unroll
+                                for (int j = 0; j < 2; j++) kin[cth][2 * u + j] = *(const gv2d_t *)(src + (size_t)(8 * j) * ld + 16 * cth);
+                        }
+                    }
+#pragma unroll
+                    for (int cth = 0; cth < 2; cth++) {
+                        const int ct = 2 * half + cth;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (ldu[u]) {
+#pragma unroll
+                                for (int j = 0; j < 2; j++) *(v2d *)&S[16 * u + 8 * j + srow8][2 * spc] = kin[cth][2 * u + j];
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
+                            if (ldu[u]) {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) acc[ct][u][r] = -S[16 * u + (lane_o & 15)][4 * r + (lane_o >> 4)];
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+#ifdef MEDGP_STAMPS
+                    if (half == 0) STAMP(1);
+#endif
+                }
+            }
+#else
             v4d acc[4][4];
 #pragma unroll
             for (int ct = 0; ct < 4; ct++)
@@ -532,48 +409,40 @@ __device__ bool cholinv_attempt_il(const MedgpDev &L, int b, int slot, int n, in
                     acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
                     if (act[u] && isM[u]) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++) acc[ct][u][r] = -Lb[(size_t)(rowb[u] + li) * ld + c0 + 16 * ct + 4 * r + g];
+                        for (int r = 0; r < 4; r++) acc[ct][u][r] = -ub[u][(size_t)li * ld + c0 + 16 * ct + 4 * r + g];
                     }
                 }
-            STAMP(0);
+#endif
+            STAMP(0);   // panel init
             double zsum = 0.0;
+            // ---- GEMM over the history, B chunk (L[C_k rows]) staged through LDS, double buffered
             if (nch > cstart) {
+                // staging: 64 x CI_KC doubles per chunk, NT threads -> 64 CI_KC / NT elements each
                 constexpr int SPT = 64 * CI_KC / NT;
                 const int srow = (tid * SPT) / CI_KC, scol = (tid * SPT) % CI_KC;
-                const double *Bsrc = Lb + (size_t)(c0 + srow) * ld + scol;
+                const gd_t *Bsrc = Lb + (size_t)(c0 + srow) * ld + scol;
                 double bnext[SPT];
 #pragma unroll
-                for (int e = 0; e < SPT; e++) { bnext[e] = Bsrc[cstart * CI_KC + e]; sm.Bs[cstart & 1][srow][scol + e] = bnext[e]; }
+                for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[cstart * CI_KC + e];
+                __syncthreads();   // every wave is done with its init slab (St aliases Bs)
+#pragma unroll
+                for (int e = 0; e < SPT; e++) sm.Bs[cstart & 1][srow][scol + e] = bnext[e];
                 __syncthreads();
-                for (int c = cstart; c < nch; c++) {
-                    const int buf = c & 1;
-                    const int nact = (c >= cf[0]) + (c >= cf[1]) + (c >= cf[2]) + (c >= cf[3]);
-                    if (nact == 4) CI_CHUNK_BODY(4)
-                    else if (nact == 3) CI_CHUNK_BODY(3)
-                    else if (nact == 2) CI_CHUNK_BODY(2)
-                    else if (nact == 1) CI_CHUNK_BODY(1)
-                    else if (c + 1 < nch) {
-#pragma unroll
-                        for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[(c + 1) * CI_KC + e];
-                    }
-                    if (pass == 0 && wave == NW - 1) {
-                        if (npad <= 1024) {
-#pragma unroll
-                            for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * sm.zs[c * CI_KC + kk];
-                        } else {
-#pragma unroll
-                            for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * zz[c * CI_KC + kk];
-                        }
-                    }
-                    STAMP(4);
-                    if (c + 1 < nch) {
-#pragma unroll
-                        for (int e = 0; e < SPT; e++) sm.Bs[buf ^ 1][srow][scol + e] = bnext[e];
-                    }
-                    STAMP(6);
-                    __syncthreads();
-                    STAMP(7);
-                }
+                // The history operand of a chunk is loaded and consumed in the same iteration: NO software prefetch.
+                // Measured: hipcc turns every use of a prefetched register into `s_waitcnt vmcnt(0)`, so a register
+                // prefetch ring hid nothing and its 32-64 extra VGPRs pushed accumulator tiles into scratch inside the
+                // loop; without it the loop is spill free and the other workgroup on the CU covers the latency.
+                // The active set only grows with c (cf ascending), so the loop runs as up to five phases with a fixed
+                // body each (one loop with a switch on the prefix length made hipcc shuffle and spill the accumulators).
+                auto clampc = [&](int v) { return v < cstart ? cstart : (v > nch ? nch : v); };
+                const int p1 = clampc(cf[0]), p2 = clampc(cf[1]), p3 = clampc(cf[2]), p4 = clampc(cf[3]);
+                CI_CHUNK_PHASE(0, cstart, p1)
+                CI_CHUNK_PHASE(1, p1, p2)
+                CI_CHUNK_PHASE(2, p2, p3)
+                CI_CHUNK_PHASE(3, p3, p4)
+                CI_CHUNK_PHASE(4, p4, nch)
+            } else {
+                __syncthreads();   // init slabs done before Dk (same LDS) is written below
             }
             STAMP(1);
             if (pass == 0) {
@@ -586,15 +455,15 @@ __device__ bool cholinv_attempt_il(const MedgpDev &L, int b, int slot, int n, in
                 }
                 if (wave == NW - 1) sm.zacc[lane] = zsum;
                 __syncthreads();
-                STAMP(0);
+                STAMP(0);   // wait for the slowest GEMM wave (folded into 0)
                 if (wave == 0) {
-                    diag_factor_wave(sm, lane);
-                    STAMP(3);
+                    diag_factor_wave(&sm.Dk[0][0], &sm.Xk[0][0], sm.rdiag, &sm.fail, &sm.logdet, lane);
+                    STAMP(3);   // diagonal factor
                     if (!sm.fail) {
+                        // z_k = L_kk^-1 (y_k - zacc).  Xk has exact zeros above the diagonal, so the fixed-length loops
+                        // below add the same terms in the same order as triangular loops, but pipeline their LDS reads
                         sm.rhs[lane] = ((c0 + lane < n) ? y[c0 + lane] : 0.0) - sm.zacc[lane];
                         __builtin_amdgcn_wave_barrier();
-                        // Xk is stored with exact zeros above the diagonal, so the fixed-length loops below add the same
-                        // terms in the same order as a triangular loop would, but pipeline their LDS reads
                         double s = 0.0;
 #pragma unroll 16
                         for (int cc = 0; cc < 64; cc++) s += sm.Xk[lane][cc] * sm.rhs[cc];
@@ -602,6 +471,7 @@ __device__ bool cholinv_attempt_il(const MedgpDev &L, int b, int slot, int n, in
                         sm.zk[lane] = s;
                         if (c0 + lane < 1024) sm.zs[c0 + lane] = s;
                         if (want_inv) {
+                            // alpha = U z accumulated panel by panel; the diagonal block U_kk = L_kk^-T opens rows C_k
                             __builtin_amdgcn_wave_barrier();
                             double a0 = 0.0;
 #pragma unroll 16
@@ -613,16 +483,24 @@ __device__ bool cholinv_attempt_il(const MedgpDev &L, int b, int slot, int n, in
                 __syncthreads();
                 STAMP(2);   // z / alpha solves of wave 0, or waiting for the diagonal phase
                 if (sm.fail) return false;
+                // store L_kk (lower) and U_kk = L_kk^-T (upper, zeros below)
                 for (int e = tid; e < 64 * 64; e += NT) {
                     int rr = e >> 6, cc = e & 63;
                     if (cc <= rr) Lb[(size_t)(c0 + rr) * ld + c0 + cc] = sm.Dk[rr][cc];
                     if (want_inv) Ub[(size_t)(c0 + rr) * ld + c0 + cc] = (cc >= rr) ? sm.Xk[cc][rr] : 0.0;
                 }
+                // Dk fully read before the store slabs (same LDS) are written: LDS-only barrier (no wait for the global
+                // stores above, which nobody reads before the next step)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
-            STAMP(3);
-            // triangular solve as GEMM on all four units (an inactive or diagonal unit computes on zeros / unused
-            // values: 40 MFMAs, never stored), stores and alpha guarded per unit
+            STAMP(3);   // L_kk / U_kk stores (folded into diag)
+            // ---- triangular solve as GEMM: out^T[ct] = sum_{ct' <= ct} (-Xk[ct, ct']) acc^T[ct'] on all four units (an
+            //      inactive or diagonal unit computes on zeros / unused values: 40 MFMAs, never stored); each 16-column
+            //      slab goes through the wave's LDS slab and leaves as whole 128-byte lines
             {
+#if CI_SLAB_STORE
+                CI_SLAB_LANE();
+#endif
                 bool st[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) st[u] = act[u] && !(pass == 0 && wg == 0 && u == 0);
@@ -640,10 +518,31 @@ __device__ bool cholinv_attempt_il(const MedgpDev &L, int b, int slot, int n, in
 #pragma unroll
                             for (int u = 0; u < 4; u++) o[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[cp][u][r], o[u], 0, 0, 0);
                         }
+#if CI_SLAB_STORE
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) S[16 * u + (lane_o & 15)][4 * r + (lane_o >> 4)] = o[u][r];
+                        if (st[u] && !isM[u]) {   // U rows: alpha_i += sum_c U[i][c] z_k[c]
+#pragma unroll
+                            for (int r = 0; r < 4; r++) pal[u] += o[u][r] * sm.zk[16 * ct + 4 * r + g];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int u = i >> 1;
+                        if (st[u]) {
+                            gd_t *Out = (isM[u] ? Lb : Ub) + (size_t)(rowb[u] + 8 * (i & 1) + srow8) * ld + c0 + 16 * ct + 2 * spc;
+                            *(gv2d_t *)Out = *(const v2d *)&S[8 * i + srow8][2 * spc];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#else
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         if (st[u]) {
-                            double *Out = (isM[u] ? Lb : Ub) + (size_t)(rowb[u] + li) * ld + c0 + 16 * ct + g;
+                            gd_t *Out = (isM[u] ? Lb : Ub) + (size_t)(rowb[u] + li) * ld + c0 + 16 * ct + g;
 #pragma unroll
                             for (int r = 0; r < 4; r++) Out[4 * r] = o[u][r];
                             if (!isM[u]) {
@@ -652,6 +551,7 @@ __device__ bool cholinv_attempt_il(const MedgpDev &L, int b, int slot, int n, in
                             }
                         }
                     }
+#endif
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -659,13 +559,17 @@ __device__ bool cholinv_attempt_il(const MedgpDev &L, int b, int slot, int n, in
                         double v = pal[u];
                         v += __shfl_xor(v, 16);
                         v += __shfl_xor(v, 32);
-                        if (g == 0) alpha[rowb[u] + li] += v;
+                        if (g == 0) alpha[rowb[u] + li] += v;   // this wave owns these rows in this step
                     }
                 }
             }
-            STAMP(5);
-            __syncthreads();
-            STAMP(5);
+            STAMP(5);   // panel solve + stores
+            // Visibility of this pass's stores: columns C_k are first read in step k + 1, at chunk 4k - 1 (B staging) or
+            // later, i.e. after >= 3 chunk barriers (each a full __syncthreads with vmcnt(0)) when k >= 1 -- no need to
+            // wait for the store acknowledgements here.  Step 1 reads C_0 right away: full barrier after step 0 only.
+            // LDS needs no barrier either: slabs are per wave, Xk / zk are next written after the next step's GEMM.
+            if (k == 0) __syncthreads();
+            STAMP(5);   // end-of-step barrier (folded into trsm)
         }
     }
 #ifdef MEDGP_STAMPS
@@ -677,19 +581,22 @@ __device__ bool cholinv_attempt_il(const MedgpDev &L, int b, int slot, int n, in
     return true;
 }
 
-
-// grid = nbatch, block = NW * 64.  NW = 16: one workgroup per CU (lowest latency per patient);
-// NW = 8: two workgroups per CU, the serial diagonal-block phase of one overlaps the MFMA phase of the other.
-template <int NW, int UPW, bool IL = false>
+// grid = nbatch, block = NW * 64.  NW = 8: one workgroup per CU (lowest latency per patient);
+// NW = 4: two workgroups per CU, the serial diagonal-block phase of one overlaps the MFMA phase of the other.
+template <int NW>
 __global__ void __launch_bounds__(NW * 64, 2) k_cholinv(MedgpDev L, int want_inv) {
     constexpr int NT = NW * 64;
-    __shared__ CholInvSmem sm;
+    __shared__ CholInvSmem<NW> sm;
     const int b = blockIdx.x, tid = threadIdx.x;
     if (L.status[b] < 0) return;
-    const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64);
+    // loaded values the whole workgroup agrees on: pin them to scalar registers, otherwise every quantity derived from
+    // n (block counts, slot tables, row bases) lives in VGPRs across the MFMA loop and its branches run on exec masks
+    const int slot = __builtin_amdgcn_readfirstlane(L.bslot[b]);
+    const int n = __builtin_amdgcn_readfirstlane(L.pn[slot]);
+    const int ld = L.ldn, npad = medgp_roundup(n, 64);
     int count = 0;
     while (true) {
-        if (IL ? cholinv_attempt_il<NW>(L, b, slot, n, want_inv, sm) : cholinv_attempt<NW, UPW>(L, b, slot, n, want_inv, sm)) break;
+        if (cholinv_attempt<NW>(L, b, slot, n, want_inv, sm)) break;
         __syncthreads();
         if (count >= 10) {   // ref: c_inference_exact.cpp:99,109-111
             if (tid == 0) L.status[b] = -1;
@@ -699,7 +606,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_cholinv(MedgpDev L, int want_inv
         reassemble_wg(L, b, slot, n, npad, count);
     }
     __syncthreads();
-    const double *zz = L.z + (size_t)b * ld;
+    const gd_t *zz = (const gd_t *)(L.z + (size_t)b * ld);
     // quad = z^T z (fixed-order tree)
     {
         double s = 0.0;

@@ -26,54 +26,11 @@ struct McSmem {
 };
 static_assert(sizeof(double) * 2 * 64 * (MC_KC + 2) >= sizeof(double) * 64 * 66, "Dk must fit in the staging buffers");
 
-// CholInvSmem-compatible view for diag_factor_wave (it only touches Dk, Xk, rdiag, logdet, fail)
-__device__ __attribute__((noinline)) void mc_diag_factor(McSmem &sm, int lane) {
-    const int li = lane & 15, g = lane >> 4;
-    double *D = &sm.Dk[0][0], *X = &sm.Xk[0][0];
-#define TD(s, t) (D + (16 * (s)) * CI_S + 16 * (t))
-#define TX(s, t) (X + (16 * (s)) * CI_S + 16 * (t))
-    double logsum = 0.0;
-    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-    for (int t = 0; t < 4; t++) {
-        if (!diag16(TD(t, t), TX(t, t), sm.rdiag, lane, &logsum)) { if (lane == 0) sm.fail = 1; return; }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-        for (int s2 = t + 1; s2 < 4; s2++) {
-            v4d c = tile_mm<false, true>(TD(s2, t), TX(t, t), zero4, li, g);
-            __builtin_amdgcn_wave_barrier();
-            tile_st(TD(s2, t), c, li, g);
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-        for (int s2 = t + 1; s2 < 4; s2++)
-#pragma unroll 1
-            for (int u = t + 1; u <= s2; u++) {
-                v4d p = tile_mm<false, true>(TD(s2, t), TD(u, t), zero4, li, g);
-                v4d c = tile_ld(TD(s2, u), li, g);
-                tile_st(TD(s2, u), c - p, li, g);
-            }
-        __builtin_amdgcn_wave_barrier();
-    }
-#pragma unroll 1
-    for (int t = 0; t < 4; t++)
-#pragma unroll 1
-        for (int s2 = t + 1; s2 < 4; s2++) {
-            v4d p = zero4;
-            for (int u = t; u < s2; u++) p = tile_mm<false, false>(TD(s2, u), TX(u, t), p, li, g);
-            tile_st(TX(s2, t), p, li, g);
-            __builtin_amdgcn_wave_barrier();
-            v4d xs = tile_mm<false, false>(TX(s2, s2), TX(s2, t), zero4, li, g);
-            __builtin_amdgcn_wave_barrier();
-            tile_st(TX(s2, t), -xs, li, g);
-            __builtin_amdgcn_wave_barrier();
-        }
-#pragma unroll 1
-    for (int t = 1; t < 4; t++)
-        for (int s2 = 0; s2 < t; s2++) tile_st(TX(s2, t), zero4, li, g);
-    if (lane == 0) sm.logdet = logsum;
-#undef TD
-#undef TX
+// the diagonal block is factored by the same single-wave tile code as k_cholinv
+__device__ inline void mc_diag_factor(McSmem &sm, int lane) {
+    if (lane == 0) sm.logdet = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    diag_factor_wave(&sm.Dk[0][0], &sm.Xk[0][0], sm.rdiag, &sm.fail, &sm.logdet, lane);
 }
 
 // grid = (max blocks, nbatch), block = 256 (4 waves x 16 rows)

@@ -5,7 +5,7 @@ import medgp_amd
 from medgp_amd import capi, synth
 capi.lib_path = lambda: '/root/repo/scratch/libmedgp_hip_stamps.so'
 D,N,Q,R=24,512,5,8
-names=['init+wait','gemmrest','zsolve|diagwait','diagfac+st','mfma','trsm+end','stagest','chunkbar']
+names=['init+wait','inithalf0','zsolve|diagwait','diagfac+st','mfma','trsm+end','stagest','chunkbar']
 for P in (512,):
     pts, th = synth.cohort(11, min(P,16), D, N, Q=Q, R=R)
     ctx = medgp_amd.Context(7, Q, D, R); ctx.reserve(P, N, P)
