@@ -111,85 +111,69 @@ __device__ inline void tile_st(double *Cp, v4d c, int li, int g) {
     for (int r = 0; r < 4; r++) Cp[(4 * r + g) * CI_S + li] = c[r];
 }
 
-// Cholesky + inverse of one 16x16 diagonal tile, register resident (lane i holds row i; lanes >= 16 mirror
-// lanes & 15), cross-lane traffic by v_readlane.  T: tile in Dk (in: D lower, out: L lower);
-// X: tile in Xk (out: full 16x16 inverse, zeros above the diagonal).  Returns false on a bad pivot
-// (LAPACK potf2 rule: pivot <= 0 or NaN).  *logsum += sum log(diag) (computed lane-parallel).
-__device__ inline bool diag16(double *T, double *X, double *rdl, int lane, double *logsum) {
-    const int i = lane & 15;
-    {
-        double a[16];
+// Cholesky + inverse of one 16x16 diagonal tile, register resident, cross-lane traffic by v_readlane.
+// Lanes 0..15 hold the rows of the tile, lanes 16..31 the rows of an appended identity: the right-looking column
+// recurrence  row[j] *= 1/l_jj;  row[c] -= row[j] l_cj (c > j)  turns the tile rows into L and the identity rows into
+// L^-T -- the inverse costs no extra instructions (the same trick k_cholinv plays with whole panels).  Lanes 32..63
+// mirror lanes 0..31.  T: tile in Dk (in: D lower, out: L lower); X: tile in Xk (out: the full 16x16 inverse, exact
+// zeros above the diagonal); dv[0..16) receives diag(L).  Returns false on a bad pivot (LAPACK potf2 rule: pivot <= 0
+// or NaN).
+__device__ inline bool diag16(double *T, double *X, double *dv, int lane) {
+    const int i = lane & 15, i5 = lane & 31;
+    const bool ident = i5 >= 16;
+    double a[16];
 #pragma unroll
-        for (int c = 0; c < 16; c++) a[c] = T[i * CI_S + c];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            double piv = readlane_d(a[j], j);
-            if (!(piv > 0.0)) return false;
-            // sqrt and reciprocal sqrt together: v_rsq_f64 seed + two coupled Goldschmidt steps + one residual
-            // correction (about 1 ulp each; pivots of a scaled covariance never need the denormal rescaling that makes
-            // the library sqrt + divide a ~450-cycle dependent chain on this serial path)
-            double sq, rinv;
-            {
-                const double y0 = __builtin_amdgcn_rsq(piv);
-                double gg = piv * y0, hh = 0.5 * y0;
-                double rr = fma(-gg, hh, 0.5);
-                gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
-                rr = fma(-gg, hh, 0.5);
-                gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
-                const double dd = fma(-gg, gg, piv);
-                sq = fma(dd, hh, gg);
-                rinv = hh + hh;
-            }
-            if (lane == j) rdl[j] = rinv;
-            a[j] = (i == j) ? sq : a[j] * rinv;
-#pragma unroll
-            for (int c = j + 1; c < 16; c++) a[c] -= a[j] * readlane_d(a[j], c);
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int c = 0; c < 16; c++)
-                if (c <= i) T[i * CI_S + c] = a[c];
-        }
-        // log-det contribution: lane j holds l_jj in a[j]; pick it without dynamic register indexing
-        double dj = a[0];
-#pragma unroll
-        for (int c = 1; c < 16; c++) dj = (i == c) ? a[c] : dj;
-        double lg = log(dj), tot = 0.0;
-#pragma unroll
-        for (int c = 0; c < 16; c++) tot += readlane_d(lg, c);
-        *logsum += tot;
+    for (int c = 0; c < 16; c++) {
+        const double t = T[i * CI_S + c];
+        a[c] = ident ? ((c == i) ? 1.0 : 0.0) : t;
     }
-    __builtin_amdgcn_wave_barrier();
-    // inverse: lane = column i of X;  x_r = -(sum_{k<r} l_rk x_k) / l_rr, x_k = 0 for k < i.
-    // L rows are read back from LDS (wave-uniform addresses: broadcast reads, no stores in between).
-    double x[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        double sacc = 0.0;
+    for (int j = 0; j < 16; j++) {
+        double piv = readlane_d(a[j], j);
+        if (!(piv > 0.0)) return false;
+        // sqrt and reciprocal sqrt together: v_rsq_f64 seed + two coupled Goldschmidt steps + one residual
+        // correction (about 1 ulp each; pivots of a scaled covariance never need the denormal rescaling that makes
+        // the library sqrt + divide a ~450-cycle dependent chain on this serial path)
+        double sq, rinv;
+        {
+            const double y0 = __builtin_amdgcn_rsq(piv);
+            double gg = piv * y0, hh = 0.5 * y0;
+            double rr = fma(-gg, hh, 0.5);
+            gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
+            rr = fma(-gg, hh, 0.5);
+            gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
+            const double dd = fma(-gg, gg, piv);
+            sq = fma(dd, hh, gg);
+            rinv = hh + hh;
+        }
+        if (lane == j) dv[j] = sq;
+        a[j] = (i5 == j) ? sq : a[j] * rinv;
 #pragma unroll
-        for (int k = 0; k < r; k++) sacc += T[r * CI_S + k] * x[k];
-        double rdr = rdl[r];
-        x[r] = (r == i) ? rdr : ((r > i) ? -sacc * rdr : 0.0);
+        for (int c = j + 1; c < 16; c++) a[c] -= a[j] * readlane_d(a[j], c);
     }
     if (lane < 16) {
 #pragma unroll
-        for (int c = 0; c < 16; c++) X[c * CI_S + i] = x[c];
+        for (int c = 0; c < 16; c++)
+            if (c <= i) T[i * CI_S + c] = a[c];
+    } else if (lane < 32) {   // identity rows: a[c] = (L^-T)[i][c] = (L^-1)[c][i], exactly zero for c < i
+#pragma unroll
+        for (int c = 0; c < 16; c++) X[c * CI_S + i] = a[c];
     }
     return true;
 }
 
 // Cholesky of the 64x64 block in sm.Dk (lower, in place) and its inverse into sm.Xk (lower), on ONE wave:
 // 16x16 tiles, diagonal tiles in registers (diag16), everything else as MFMA tile products out of LDS.
-// D, X: 64 x 64 with row stride CI_S; rdiag: 16 doubles of scratch; *fail is set on a bad pivot; *logdet += sum log diag.
-__device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X, double *rdiag, int *fail, double *logdet, int lane) {
+// D, X: 64 x 64 with row stride CI_S; dv: 64 doubles of scratch (diag of L); *fail is set on a bad pivot;
+// *logdet += sum log diag (one lane-parallel log + a fixed butterfly over the 64 pivots).
+__device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X, double *dv, int *fail, double *logdet, int lane) {
     const int li = lane & 15, g = lane >> 4;
 #define TD(s, t) (D + (16 * (s)) * CI_S + 16 * (t))
 #define TX(s, t) (X + (16 * (s)) * CI_S + 16 * (t))
-    double logsum = 0.0;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
     for (int t = 0; t < 4; t++) {
-        if (!diag16(TD(t, t), TX(t, t), rdiag, lane, &logsum)) { if (lane == 0) *fail = 1; return; }
+        if (!diag16(TD(t, t), TX(t, t), dv + 16 * t, lane)) { if (lane == 0) *fail = 1; return; }
         __builtin_amdgcn_wave_barrier();
         // panel below: L(s,t) = D(s,t) X(t,t)^T
 #pragma unroll 1
@@ -229,7 +213,11 @@ __device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X,
 #pragma unroll 1
     for (int t = 1; t < 4; t++)
         for (int s2 = 0; s2 < t; s2++) tile_st(TX(s2, t), zero4, li, g);
-    if (lane == 0) *logdet += logsum;
+    __builtin_amdgcn_wave_barrier();
+    double lg = log(dv[lane]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
+    if (lane == 0) *logdet += lg;
 #undef TD
 #undef TX
 }
@@ -457,7 +445,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 __syncthreads();
                 STAMP(0);   // wait for the slowest GEMM wave (folded into 0)
                 if (wave == 0) {
-                    diag_factor_wave(&sm.Dk[0][0], &sm.Xk[0][0], sm.rdiag, &sm.fail, &sm.logdet, lane);
+                    diag_factor_wave(&sm.Dk[0][0], &sm.Xk[0][0], sm.rhs, &sm.fail, &sm.logdet, lane);
                     STAMP(3);   // diagonal factor
                     if (!sm.fail) {
                         // z_k = L_kk^-1 (y_k - zacc).  Xk has exact zeros above the diagonal, so the fixed-length loops

@@ -30,7 +30,7 @@ static_assert(sizeof(double) * 2 * 64 * (MC_KC + 2) >= sizeof(double) * 64 * 66,
 __device__ inline void mc_diag_factor(McSmem &sm, int lane) {
     if (lane == 0) sm.logdet = 0.0;
     __builtin_amdgcn_wave_barrier();
-    diag_factor_wave(&sm.Dk[0][0], &sm.Xk[0][0], sm.rdiag, &sm.fail, &sm.logdet, lane);
+    diag_factor_wave(&sm.Dk[0][0], &sm.Xk[0][0], sm.rhs, &sm.fail, &sm.logdet, lane);
 }
 
 // grid = (max blocks, nbatch), block = 256 (4 waves x 16 rows)
