@@ -117,7 +117,8 @@ __device__ inline void tile_st(double *Cp, v4d c, int li, int g) {
 // L^-T -- the inverse costs no extra instructions (the same trick k_cholinv plays with whole panels).  Lanes 32..63
 // mirror lanes 0..31.  T: tile in Dk (in: D lower, out: L lower); X: tile in Xk (out: the full 16x16 inverse, exact
 // zeros above the diagonal); dv[0..16) receives diag(L).  Returns false on a bad pivot (LAPACK potf2 rule: pivot <= 0
-// or NaN).
+// or NaN); there is no early exit -- the 16 steps are ONE basic block, so the column updates of step j overlap the
+// reciprocal-square-root chain of step j + 1 (a bad pivot just propagates NaNs that nobody uses).
 __device__ inline bool diag16(double *T, double *X, double *dv, int lane) {
     const int i = lane & 15, i5 = lane & 31;
     const bool ident = i5 >= 16;
@@ -127,31 +128,30 @@ __device__ inline bool diag16(double *T, double *X, double *dv, int lane) {
         const double t = T[i * CI_S + c];
         a[c] = ident ? ((c == i) ? 1.0 : 0.0) : t;
     }
+    bool ok = true;
+    double dj = 1.0;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        double piv = readlane_d(a[j], j);
-        if (!(piv > 0.0)) return false;
+        const double piv = readlane_d(a[j], j);
+        ok = ok && (piv > 0.0);
         // sqrt and reciprocal sqrt together: v_rsq_f64 seed + two coupled Goldschmidt steps + one residual
         // correction (about 1 ulp each; pivots of a scaled covariance never need the denormal rescaling that makes
         // the library sqrt + divide a ~450-cycle dependent chain on this serial path)
-        double sq, rinv;
-        {
-            const double y0 = __builtin_amdgcn_rsq(piv);
-            double gg = piv * y0, hh = 0.5 * y0;
-            double rr = fma(-gg, hh, 0.5);
-            gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
-            rr = fma(-gg, hh, 0.5);
-            gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
-            const double dd = fma(-gg, gg, piv);
-            sq = fma(dd, hh, gg);
-            rinv = hh + hh;
-        }
-        if (lane == j) dv[j] = sq;
+        const double y0 = __builtin_amdgcn_rsq(piv);
+        double gg = piv * y0, hh = 0.5 * y0;
+        double rr = fma(-gg, hh, 0.5);
+        gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
+        rr = fma(-gg, hh, 0.5);
+        gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
+        const double dd = fma(-gg, gg, piv);
+        const double sq = fma(dd, hh, gg), rinv = hh + hh;
+        dj = (i5 == j) ? sq : dj;
         a[j] = (i5 == j) ? sq : a[j] * rinv;
 #pragma unroll
         for (int c = j + 1; c < 16; c++) a[c] -= a[j] * readlane_d(a[j], c);
     }
     if (lane < 16) {
+        dv[lane] = dj;
 #pragma unroll
         for (int c = 0; c < 16; c++)
             if (c <= i) T[i * CI_S + c] = a[c];
@@ -159,65 +159,135 @@ __device__ inline bool diag16(double *T, double *X, double *dv, int lane) {
 #pragma unroll
         for (int c = 0; c < 16; c++) X[c * CI_S + i] = a[c];
     }
-    return true;
+    return ok;
 }
 
-// Cholesky of the 64x64 block in sm.Dk (lower, in place) and its inverse into sm.Xk (lower), on ONE wave:
-// 16x16 tiles, diagonal tiles in registers (diag16), everything else as MFMA tile products out of LDS.
-// D, X: 64 x 64 with row stride CI_S; dv: 64 doubles of scratch (diag of L); *fail is set on a bad pivot;
-// *logdet += sum log diag (one lane-parallel log + a fixed butterfly over the 64 pivots).
+#ifdef MEDGP_STAMPS
+__device__ unsigned long long g_diag_dbg[8];
+#define DSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (lane == 0) atomicAdd(&g_diag_dbg[k], t_ - dlast); dlast = t_; } while (0)
+#else
+#define DSTAMP(k) do {} while (0)
+#endif
+// Cholesky of the 64x64 block D (lower, in place) and its inverse into X (lower), on ONE wave: 16x16 tiles, diagonal
+// tiles in registers (diag16), everything else as MFMA tile products.  D, X: row stride CI_S; dv: 64 doubles of scratch
+// (diag of L); *fail is set on a bad pivot; *logdet += sum log diag (one lane-parallel log + a fixed butterfly).
+// Register-level operand reuse (v_mfma_f64_16x16x4_f64: A lane (i = l & 15, k = l >> 4), B lane (k = l >> 4, j = l & 15),
+// C/D lane (col = l & 15, row = (l >> 4) + 4 reg)):  a C-layout tile c, used register by register as the operand of
+// k-step r, is the matrix c^T as an A operand and the matrix c itself as a B operand.  The panel tiles are therefore
+// computed TRANSPOSED (lt = X(t,t) D(s,t)^T = L(s,t)^T): lt is at once the A operand L(s,t) and the B operand L(u,t)^T of
+// the trailing update, and the partial sums P of the inverse feed X(s,s) P straight from their accumulators -- no LDS
+// round trips between dependent products, and all LDS reads of a stage are issued before its MFMAs.
 __device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X, double *dv, int *fail, double *logdet, int lane) {
     const int li = lane & 15, g = lane >> 4;
 #define TD(s, t) (D + (16 * (s)) * CI_S + 16 * (t))
 #define TX(s, t) (X + (16 * (s)) * CI_S + 16 * (t))
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+#ifdef MEDGP_STAMPS
+    unsigned long long dlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
+#endif
 #pragma unroll 1
     for (int t = 0; t < 4; t++) {
         if (!diag16(TD(t, t), TX(t, t), dv + 16 * t, lane)) { if (lane == 0) *fail = 1; return; }
         __builtin_amdgcn_wave_barrier();
-        // panel below: L(s,t) = D(s,t) X(t,t)^T
-#pragma unroll 1
-        for (int s2 = t + 1; s2 < 4; s2++) {
-            v4d c = tile_mm<false, true>(TD(s2, t), TX(t, t), zero4, li, g);
-            __builtin_amdgcn_wave_barrier();
-            tile_st(TD(s2, t), c, li, g);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // trailing: D(s,u) -= L(s,t) L(u,t)^T
-#pragma unroll 1
-        for (int s2 = t + 1; s2 < 4; s2++)
-#pragma unroll 1
-            for (int u = t + 1; u <= s2; u++) {
-                v4d p = tile_mm<false, true>(TD(s2, t), TD(u, t), zero4, li, g);
-                v4d c = tile_ld(TD(s2, u), li, g);
-                tile_st(TD(s2, u), c - p, li, g);
+        DSTAMP(0);
+        if (t == 3) break;
+        // ---- panel below, transposed:  lt[si] = X(t,t) D(s,t)^T = L(s,t)^T,  s = t + 1 + si
+        double xa[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) xa[k] = TX(t, t)[li * CI_S + 4 * k + g];
+        double db[3][4];
+#pragma unroll
+        for (int si = 0; si < 3; si++)
+            if (t + 1 + si < 4) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) db[si][k] = TD(t + 1 + si, t)[li * CI_S + 4 * k + g];
             }
+        // trailing tiles D(s,u), t < u <= s, fetched while the panel products run
+        v4d dc[3][3];
+#pragma unroll
+        for (int si = 0; si < 3; si++)
+#pragma unroll
+            for (int ui = 0; ui <= si; ui++)
+                if (t + 1 + si < 4) dc[si][ui] = tile_ld(TD(t + 1 + si, t + 1 + ui), li, g);
+        v4d lt[3];
+#pragma unroll
+        for (int si = 0; si < 3; si++) lt[si] = zero4;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int si = 0; si < 3; si++)
+                if (t + 1 + si < 4) lt[si] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k], db[si][k], lt[si], 0, 0, 0);
+#pragma unroll
+        for (int si = 0; si < 3; si++)
+            if (t + 1 + si < 4) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) TD(t + 1 + si, t)[li * CI_S + 4 * r + g] = lt[si][r];   // L(s,t), untransposed
+            }
+        DSTAMP(1);
+        // ---- trailing update  D(s,u) -= L(s,t) L(u,t)^T  straight from the lt registers
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int si = 0; si < 3; si++)
+#pragma unroll
+                for (int ui = 0; ui <= si; ui++)
+                    if (t + 1 + si < 4) dc[si][ui] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lt[si][r], lt[ui][r], dc[si][ui], 0, 0, 0);
+#pragma unroll
+        for (int si = 0; si < 3; si++)
+#pragma unroll
+            for (int ui = 0; ui <= si; ui++)
+                if (t + 1 + si < 4) tile_st(TD(t + 1 + si, t + 1 + ui), dc[si][ui], li, g);
+        __builtin_amdgcn_wave_barrier();
+        DSTAMP(2);
+    }
+    // ---- inverse, block row s:  X(s,t) = -X(s,s) P,  P = sum_{u=t}^{s-1} L(s,u) X(u,t)  (chains t < s are independent)
+#pragma unroll
+    for (int s2 = 1; s2 < 4; s2++) {
+        v4d pp[3];
+#pragma unroll
+        for (int t = 0; t < s2; t++) pp[t] = zero4;
+#pragma unroll
+        for (int u = 0; u < s2; u++) {
+            double la[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) la[k] = TD(s2, u)[li * CI_S + 4 * k + g];
+#pragma unroll
+            for (int t = 0; t <= u; t++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    pp[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[k], TX(u, t)[(4 * k + g) * CI_S + li], pp[t], 0, 0, 0);
+            }
+        }
+        double xs[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) xs[r] = -TX(s2, s2)[li * CI_S + 4 * r + g];
+        v4d xo[3];
+#pragma unroll
+        for (int t = 0; t < s2; t++) xo[t] = zero4;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int t = 0; t < s2; t++) xo[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[r], pp[t][r], xo[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < s2; t++) tile_st(TX(s2, t), xo[t], li, g);
         __builtin_amdgcn_wave_barrier();
     }
-    // inverse, block column t: X(s,t) = -X(s,s) sum_{u=t}^{s-1} L(s,u) X(u,t)
-#pragma unroll 1
-    for (int t = 0; t < 4; t++)
-#pragma unroll 1
-        for (int s2 = t + 1; s2 < 4; s2++) {
-            v4d p = zero4;
-            for (int u = t; u < s2; u++) p = tile_mm<false, false>(TD(s2, u), TX(u, t), p, li, g);
-            // stage P through the (still unused) tile X(s,t) to use it as a B operand
-            tile_st(TX(s2, t), p, li, g);
-            __builtin_amdgcn_wave_barrier();
-            v4d xs = tile_mm<false, false>(TX(s2, s2), TX(s2, t), zero4, li, g);
-            __builtin_amdgcn_wave_barrier();
-            tile_st(TX(s2, t), -xs, li, g);
-            __builtin_amdgcn_wave_barrier();
-        }
+    DSTAMP(3);
     // zero the strictly-upper tiles of X (U_kk is exported from X with zeros)
-#pragma unroll 1
+#pragma unroll
     for (int t = 1; t < 4; t++)
+#pragma unroll
         for (int s2 = 0; s2 < t; s2++) tile_st(TX(s2, t), zero4, li, g);
     __builtin_amdgcn_wave_barrier();
     double lg = log(dv[lane]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
     if (lane == 0) *logdet += lg;
+    DSTAMP(4);
+#ifdef MEDGP_STAMPS
+    if (lane == 0) atomicAdd(&g_diag_dbg[7], 1ull);
+#endif
 #undef TD
 #undef TX
 }
@@ -522,6 +592,9 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                         const int u = i >> 1;
                         if (st[u]) {
                             gd_t *Out = (isM[u] ? Lb : Ub) + (size_t)(rowb[u] + 8 * (i & 1) + srow8) * ld + c0 + 16 * ct + 2 * spc;
+#ifdef CI_EXP_NOSTORE
+                            if (L.ldn < 0)   // diagnostic: never true
+#endif
                             *(gv2d_t *)Out = *(const v2d *)&S[8 * i + srow8][2 * spc];
                         }
                     }

@@ -252,18 +252,19 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
     if (getenv("MEDGP_DBG_NOWGRAD")) { HIPCHK(c, hipGetLastError()); return MEDGP_OK; }
 #endif
     if (flag_grad) {
-        const dim3 tg(nbatch, tri(nt64)), tb(WG_THREADS);
+        const int wg_tiles = tri(nt64);
+        const dim3 tg(8 * ((nbatch + 7) / 8) * wg_tiles), tb(WG_THREADS);
         from_slab = 1;
         Launcher *lw = new Launcher(c, KID_WGRAD, stream);
         switch (c->use_v0 ? 0 : L.Q) {
-        case 1: hipLaunchKernelGGL(k_wgrad<1>, tg, tb, 0, stream, L); break;
-        case 2: hipLaunchKernelGGL(k_wgrad<2>, tg, tb, 0, stream, L); break;
-        case 3: hipLaunchKernelGGL(k_wgrad<3>, tg, tb, 0, stream, L); break;
-        case 4: hipLaunchKernelGGL(k_wgrad<4>, tg, tb, 0, stream, L); break;
-        case 5: hipLaunchKernelGGL(k_wgrad<5>, tg, tb, 0, stream, L); break;
-        case 6: hipLaunchKernelGGL(k_wgrad<6>, tg, tb, 0, stream, L); break;
-        case 7: hipLaunchKernelGGL(k_wgrad<7>, tg, tb, 0, stream, L); break;
-        case 8: hipLaunchKernelGGL(k_wgrad<8>, tg, tb, 0, stream, L); break;
+        case 1: hipLaunchKernelGGL(k_wgrad<1>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
+        case 2: hipLaunchKernelGGL(k_wgrad<2>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
+        case 3: hipLaunchKernelGGL(k_wgrad<3>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
+        case 4: hipLaunchKernelGGL(k_wgrad<4>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
+        case 5: hipLaunchKernelGGL(k_wgrad<5>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
+        case 6: hipLaunchKernelGGL(k_wgrad<6>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
+        case 7: hipLaunchKernelGGL(k_wgrad<7>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
+        case 8: hipLaunchKernelGGL(k_wgrad<8>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
         default: from_slab = 0; break;   // Q > 8 (or MEDGP_V0): generic kernels below
         }
         if (from_slab) delete lw; else { lw->kid = -1; delete lw; }
@@ -415,7 +416,11 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_all(c);
     c->max_slots = max_slots; c->max_n = max_n; c->max_batch = max_batch;
-    const int ldn = medgp_roundup(max_n, 64);
+    // leading dimension: padded by 16 doubles (one 128-byte line) so that the row stride is NOT a power of two.  With
+    // ld = 512 every row of every matrix of every batch entry starts in the same few HBM channels and the panel-shaped
+    // accesses of k_cholinv / k_wgrad (16 - 64 rows x a few hundred bytes) serialise on them.
+    static const int ld_pad = getenv("MEDGP_LD_PAD") ? atoi(getenv("MEDGP_LD_PAD")) : 0;
+    const int ldn = medgp_roundup(max_n, 64) + ld_pad;
     c->ldn = ldn;
     const size_t S = max_slots, B = max_batch, Q = c->Q, D = c->D, H = c->H;
     int rc;
@@ -679,6 +684,15 @@ int medgp_fit_predict_batch(medgp_ctx *c, int nbatch, const int32_t *slots, cons
 }
 
 #ifdef MEDGP_STAMPS
+// diagnostic build only: read (and clear) the phase counters of diag_factor_wave
+#ifdef MEDGP_STAMPS
+extern "C" int medgp_debug_read_diag(unsigned long long *out) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_dbg), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag_dbg), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 // diagnostic build only: copy out the stamp words k_cholinv left in the slab of batch entry b
 int medgp_debug_read_slab(medgp_ctx *c, int b, void *out, int nbytes) {
     HIPCHK(c, hipStreamSynchronize(c->stream));

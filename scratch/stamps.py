@@ -6,7 +6,7 @@ from medgp_amd import capi, synth
 capi.lib_path = lambda: '/root/repo/scratch/libmedgp_hip_stamps.so'
 D,N,Q,R=24,512,5,8
 names=['init+wait','inithalf0','zsolve|diagwait','diagfac+st','mfma','trsm+end','stagest','chunkbar']
-for P in (512,):
+for P in (int(os.environ.get("SP","512")),):
     pts, th = synth.cohort(11, min(P,16), D, N, Q=Q, R=R)
     ctx = medgp_amd.Context(7, Q, D, R); ctx.reserve(P, N, P)
     for s in range(P): ctx.set_patient(s, *pts[s % len(pts)])
@@ -15,7 +15,7 @@ for P in (512,):
     lib=capi.load()
     for it in range(2):
         lib.medgp_nlml_grad(ctx._h, P, slots.ctypes.data_as(C.POINTER(C.c_int32)), th.ctypes.data_as(C.POINTER(C.c_double)), 1, nl.ctypes.data_as(C.POINTER(C.c_double)), g.ctypes.data_as(C.POINTER(C.c_double)), st.ctypes.data_as(C.POINTER(C.c_int32)))
-    nw = 8 if P <= 256 else 4
+    nw = 4
     for b in (0, 1, min(P-1, 40)):
         buf=np.zeros(nw*8, np.uint64)
         lib.medgp_debug_read_slab.argtypes=[C.c_void_p, C.c_int, C.c_void_p, C.c_int]
