@@ -491,7 +491,15 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
     const size_t wds = from_slab ? 1 : (size_t)ld + 1;
     if (flag_grad && from_slab) {
         // add the pieces written by k_wgrad in a fixed order: rows pieces outer, column pieces inner
-        const int *roff = L.proff + (size_t)slot * (D + 1), *coff = L.pcoff + (size_t)slot * (D + 1);
+        // offset tables -> LDS first: every bin below would otherwise start with a chain of dependent global loads
+        __shared__ int s_roff[MEDGP_MAX_D + 1], s_coff[MEDGP_MAX_D + 1], s_seg[MEDGP_MAX_D + 1];
+        for (int i = tid; i <= D; i += nt) {
+            s_roff[i] = L.proff[(size_t)slot * (D + 1) + i];
+            s_coff[i] = L.pcoff[(size_t)slot * (D + 1) + i];
+            s_seg[i] = L.pseg[(size_t)slot * (D + 1) + i];
+        }
+        __syncthreads();
+        const int *roff = s_roff, *coff = s_coff, *seg = s_seg;
         const double *slab = L.slab + (size_t)b * L.slab_stride;
         const int nbins = D * (D + 1) / 2;
         for (int idx = tid; idx < 3 * Q * nbins; idx += nt) {
@@ -510,6 +518,27 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
             const int pl = pq / Q, q = pq - pl * Q;
             double *dst = (pl == 0 ? L.S : (pl == 1 ? L.SM : L.SV)) + (size_t)b * Q * D * D;
             dst[(size_t)q * D * D + d * D + e] = s;
+        }
+        __syncthreads();
+    }
+    // the 2Q frequency / length-scale gradients are D(D+1)/2-term contractions  sum B_q o SM_q,  sum B_q o SV_q : one wave
+    // each (lanes stride over the bins, fixed butterfly) instead of one thread each -- left to single threads they were
+    // the critical path of this kernel (300 dependent load pairs at D = 24 while 246 threads idled)
+    __shared__ double smuv[64];
+    const bool par_muv = flag_grad && L.kidx == 7 && 2 * Q <= 64;
+    if (par_muv) {
+        const int nbins = D * (D + 1) / 2, lane = tid & 63, nwave = nt >> 6;
+        for (int w2 = tid >> 6; w2 < 2 * Q; w2 += nwave) {
+            const int q = (w2 < Q) ? w2 : w2 - Q;
+            const double *X = ((w2 < Q) ? SM : SV) + (size_t)q * D * D, *Bq = B + (size_t)q * D * D;
+            double sacc = 0.0;
+            for (int idx = lane; idx < nbins; idx += 64) {
+                int d, e;
+                tile_decode(idx, d, e);
+                sacc += ((d == e) ? 1.0 : 2.0) * Bq[d * D + e] * X[d * D + e];
+            }
+            for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off);
+            if (lane == 0) smuv[w2] = sacc;
         }
         __syncthreads();
     }
@@ -542,11 +571,14 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
                     if (flag_grad) {
                         bool is_mu = hc < Q * (D * R + 1);
                         int q = is_mu ? hc - Q * D * R : hc - Q * (D * R + 1);
-                        const double *X = (is_mu ? SM : SV) + (size_t)q * D * D, *Bq = B + (size_t)q * D * D;
-                        double s = 0.0;
-                        for (int d = 0; d < D; d++)
-                            for (int e = 0; e <= d; e++) s += ((d == e) ? 1.0 : 2.0) * Bq[d * D + e] * X[d * D + e];
-                        gv = 0.5 * s;
+                        if (par_muv) gv = 0.5 * smuv[is_mu ? q : Q + q];
+                        else {
+                            const double *X = (is_mu ? SM : SV) + (size_t)q * D * D, *Bq = B + (size_t)q * D * D;
+                            double s = 0.0;
+                            for (int d = 0; d < D; d++)
+                                for (int e = 0; e <= d; e++) s += ((d == e) ? 1.0 : 2.0) * Bq[d * D + e] * X[d * D + e];
+                            gv = 0.5 * s;
+                        }
                     }
                 } else {
                     hv = exp(th[h]);

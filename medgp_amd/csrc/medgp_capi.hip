@@ -343,6 +343,7 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     int nc = num_cov(kernel_index, Q, D, R);
     if (nc < 0) return fail(nullptr, MEDGP_ERR_ARG, "unsupported kernel_index %d (supported: 0 SE, 7 LMC-SM, 8 SM)", kernel_index);
     if (Q < 1 || D < 1 || R < 0) return fail(nullptr, MEDGP_ERR_ARG, "bad Q/D/R = %d/%d/%d", Q, D, R);
+    if (D > MEDGP_MAX_D) return fail(nullptr, MEDGP_ERR_ARG, "D = %d exceeds the supported %d outputs", D, MEDGP_MAX_D);
     int ndev = medgp_device_count();
     if (ndev <= 0) return fail(nullptr, MEDGP_ERR_NODEVICE, "no HIP device visible; libmedgp_hip has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(nullptr, MEDGP_ERR_ARG, "device %d outside [0, %d)", device, ndev);

@@ -14,6 +14,8 @@
 
 #define MEDGP_TILE 64
 
+#define MEDGP_MAX_D 256   // outputs per context (per-output offset tables are staged in LDS)
+
 struct MedgpPrior {          // one hyper of one slot
     float p0, p1;
     int8_t type;             // -1 none, 0 clamp, 1 normal, 2 laplace  (ref: prior/c_prior.h:50-53)
