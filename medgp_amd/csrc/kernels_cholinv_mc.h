@@ -33,15 +33,18 @@ __device__ inline void mc_diag_factor(McSmem &sm, int lane) {
     diag_factor_wave(&sm.Dk[0][0], &sm.Xk[0][0], sm.rhs, &sm.fail, &sm.logdet, lane);
 }
 
-// grid = (max blocks, nbatch), block = 256 (4 waves x 16 rows)
+// grid = (nbatch, max blocks), block = 256 (4 waves x 16 rows)
 __global__ void __launch_bounds__(MC_THREADS) k_ci_panel(MedgpDev L, int k, int want_inv) {
     __shared__ McSmem sm;
-    const int b = blockIdx.y;
+    // grid = (nbatch, blocks): block-slot major, so the diagonal-block workgroups of ALL patients (slot 0: GEMM + the
+    // serial 64x64 factorisation, the long pole of the launch) are dispatched first and the history-only workgroups fill
+    // in behind them by decreasing history length
+    const int b = blockIdx.x;
     if (L.status[b] < 0) return;
     const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
     if (k >= nb) return;
     const int nM = nb - k, ntot = nM + (want_inv ? k : 0);
-    const int bidx = blockIdx.x;
+    const int bidx = blockIdx.y;
     if (bidx >= ntot) return;
     const bool isM = bidx < nM, is_diag = (bidx == 0);
     const int rblk = isM ? (k + bidx) : (bidx - nM);

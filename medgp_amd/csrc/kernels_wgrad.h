@@ -38,15 +38,25 @@ __global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L, int nbatch, in
     // (3 x 1.2 MB of U fits its 4 MB L2).  Patient-major over the whole batch instead (all patients' tile 0, then tile
     // 1, ...) cycles 64 patients x 1.2 MB through each L2 between two tiles of the same patient: every tile re-read U
     // from HBM (PMC: 3.6 GB fetched per launch for 0.6 GB of U).
-    const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int b = (rest / ntiles) * 8 + xcd;
+    // With fewer than 64 patients that would leave XCDs idle (one patient = one XCD): spread instead, patient index
+    // fastest (tiles of a patient then land on XCD b % 8 only when nbatch is a multiple of 8, which no longer matters).
+    int b, tix;
+    if (nbatch >= 64) {
+        const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+        b = (rest / ntiles) * 8 + xcd;
+        tix = rest % ntiles;
+    } else {
+        b = blockIdx.x % nbatch;
+        tix = blockIdx.x / nbatch;
+        if (tix >= ntiles) return;
+    }
     if (b >= nbatch) return;
     if (L.status[b] < 0) return;
     const int slot = __builtin_amdgcn_readfirstlane(L.bslot[b]);
     const int n = __builtin_amdgcn_readfirstlane(L.pn[slot]);
     const int ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
     int I, J;
-    tile_decode(rest % ntiles, I, J);
+    tile_decode(tix, I, J);
     if (I >= nb) return;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

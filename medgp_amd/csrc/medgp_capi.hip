@@ -204,7 +204,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         for (int attempt = 0;; attempt++) {
             launch_assemble();
             for (int k = 0; k < nt64; k++) {
-                { Launcher l(c, KID_CI_PANEL, stream); hipLaunchKernelGGL(k_ci_panel, dim3(nt64, nbatch), dim3(MC_THREADS), 0, stream, L, k, inv ? 1 : 0); }
+                { Launcher l(c, KID_CI_PANEL, stream); hipLaunchKernelGGL(k_ci_panel, dim3(nbatch, nt64), dim3(MC_THREADS), 0, stream, L, k, inv ? 1 : 0); }
                 if (nt64 > 1) { Launcher l(c, KID_CI_TRSM, stream); hipLaunchKernelGGL(k_ci_trsm, dim3(nt64 - 1, nbatch), dim3(MC_THREADS), 0, stream, L, k, inv ? 1 : 0); }
             }
             hipLaunchKernelGGL(k_ci_finish, dim3(nbatch), dim3(256), 0, stream, L);
