@@ -23,9 +23,12 @@
 
 #define WG_KC 32
 #define WG_THREADS 256
+#ifndef WG_MINWAVES
+#define WG_MINWAVES 3
+#endif
 
 template <int QT>
-__global__ void __launch_bounds__(WG_THREADS) k_wgrad(MedgpDev L, int nbatch, int ntiles) {
+__global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, int nbatch, int ntiles) {
     // staging buffers (phase 1) and the W tile (phase 2/3) share storage
     __shared__ __attribute__((aligned(16))) double smem[2 * 64 * (WG_KC + 2)];
     typedef double (*BsT)[64][WG_KC + 2];
