@@ -379,6 +379,9 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
     const long exp_off = ((long)(b % CI_EXP_ALIAS) - (long)b) * ld * ld;
     const double exp_zero = (L.ldn < 0) ? 1.0 : 0.0;   // opaque zero
 #endif
+#ifdef CI_EXP_KALIAS
+    const double kzero = (L.ldn < 0) ? 1.0 : 0.0;
+#endif
     if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
     __syncthreads();
 #ifdef MEDGP_STAMPS
@@ -467,7 +470,22 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
                     if (act[u] && isM[u]) {
 #pragma unroll
+#ifdef CI_EXP_KALIAS   // diagnostic: off-diagonal K blocks read from batch entry b % CI_EXP_KALIAS, scaled by zero
+                        for (int r = 0; r < 4; r++) {
+                            const bool dg = (pass == 0 && wg == 0 && u == 0);
+                            const long koff = dg ? 0 : ((long)(b % (CI_EXP_KALIAS ? CI_EXP_KALIAS : 1)) - (long)b) * ld * ld;
+#if CI_EXP_KALIAS == 0   // no off-diagonal loads at all
+                            double kv = 0.0;
+                            if (dg) kv = ub[u][(size_t)li * ld + c0 + 16 * ct + 4 * r + g];
+                            (void)koff;
+#else
+                            const double kv = ub[u][koff + (size_t)li * ld + c0 + 16 * ct + 4 * r + g];
+#endif
+                            acc[ct][u][r] = dg ? -kv : kv * kzero;
+                        }
+#else
                         for (int r = 0; r < 4; r++) acc[ct][u][r] = -ub[u][(size_t)li * ld + c0 + 16 * ct + 4 * r + g];
+#endif
                     }
                 }
 #endif

@@ -315,3 +315,28 @@ def test_fit_predict_batch_matches_single_calls():
         m1, v1, s1 = ctx.fit_predict(p, th[p], m2[p:p + 1], t2[p:p + 1])
         assert m1[0] == mean[p] and v1[0] == var[p]
     ctx.close()
+
+
+@pytest.mark.parametrize("P,N,force_single", [
+    (67, 130, True),     # >= 64 entries, not a multiple of 8: XCD-local tile order of k_wgrad with a ragged last group
+    (261, 200, False),   # more entries than CUs: two 4-wave workgroups per CU, several passes per step
+    (5, 330, True),      # few entries on the single-workgroup kernel: 8-wave shape, spread tile order
+])
+def test_batch_shapes_of_the_kernel_variants(P, N, force_single, monkeypatch):
+    """Every launch-shape branch of k_cholinv / k_wgrad against the oracle: ragged n (each patient has its own n <= N),
+    batch sizes on both sides of the 64-entry and #CU thresholds."""
+    if force_single:
+        monkeypatch.setenv("MEDGP_MULTI_CU", "-1")
+    D, Q, R = 6, 3, 2
+    rng = np.random.default_rng(5)
+    pts, th = synth.cohort(303, P, D, N, Q=Q, R=R)
+    pts = [(m[:k], t[:k], y[:k]) for (m, t, y), k in zip(pts, rng.integers(N // 2, N + 1, size=P))]
+    ctx = make_ctx(7, Q, D, R, pts)
+    nlml, grad, st = ctx.nlml_grad(np.arange(P), th, True)
+    nlml0, _, st0 = ctx.nlml_grad(np.arange(P), th, False)
+    assert (st == 0).all() and (st0 == 0).all()
+    assert np.array_equal(nlml0, nlml)
+    for p in list(range(0, P, max(P // 6, 1))) + [P - 1]:
+        m, t, y = pts[p]
+        assert_parity(nlml[p], grad[p], O.nlml_grad(7, Q, D, R, m, t, y, th[p], nthreads=4), f"p{p}")
+    ctx.close()
