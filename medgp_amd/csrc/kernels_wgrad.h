@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, i
     for (int ct = 0; ct < 4; ct++) acc[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
     {
         const int k0 = 64 * I, nch = (npad - k0) / WG_KC;
+        const int ctmax = (I == J) ? w : 3;   // wave-uniform
         const double *Arow = U + (size_t)(64 * I + 16 * w + li) * ld + k0 + 2 * g;
         const int srow = tid >> 2, scg = (tid & 3) * 8;
         const double *Bsrc = U + (size_t)(64 * J + srow) * ld + k0 + scg;
@@ -104,6 +105,7 @@ __global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, i
             for (int h = 0; h < 4; h++)
 #pragma unroll
                 for (int ct = 0; ct < 4; ct++) {
+                    if (ct > ctmax) continue;   // diagonal tile: columns right of this wave's rows are never used
                     const v2d bf = *(const v2d *)&Bs[buf][16 * ct + li][8 * h + 2 * g];
 #pragma unroll
                     for (int s = 0; s < 2; s++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[h][s], bf[s], acc[ct], 0, 0, 0);
