@@ -417,11 +417,9 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_all(c);
     c->max_slots = max_slots; c->max_n = max_n; c->max_batch = max_batch;
-    // leading dimension: padded by 16 doubles (one 128-byte line) so that the row stride is NOT a power of two.  With
-    // ld = 512 every row of every matrix of every batch entry starts in the same few HBM channels and the panel-shaped
-    // accesses of k_cholinv / k_wgrad (16 - 64 rows x a few hundred bytes) serialise on them.
-    static const int ld_pad = getenv("MEDGP_LD_PAD") ? atoi(getenv("MEDGP_LD_PAD")) : 0;
-    const int ldn = medgp_roundup(max_n, 64) + ld_pad;
+    // leading dimension = padded n.  (Padding it off the power of two was measured: no effect -- the HBM channel hash
+    // already spreads the 4096-byte row stride.)
+    const int ldn = medgp_roundup(max_n, 64);
     c->ldn = ldn;
     const size_t S = max_slots, B = max_batch, Q = c->Q, D = c->D, H = c->H;
     int rc;
