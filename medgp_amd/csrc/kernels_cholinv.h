@@ -50,20 +50,17 @@ typedef __attribute__((address_space(1))) v2d gv2d_t;
         (void)t_;                                                                                  \
     } while (0)
 #endif
-#ifndef CI_SLAB_INIT
-#define CI_SLAB_INIT 0   // 1: init through the slab too (coalesced, but hipcc then spills accumulator tiles in the MFMA loop: 2.2 vs 1.8 ms)
-#endif
 #ifndef CI_SLAB_STORE
 #define CI_SLAB_STORE 1
 #endif
 #define CI_ST 18          // row stride (doubles) of a wave's transposition slab: 144 B keeps 16-byte alignment
 
-template <int NW>
+template <int NW, int UPW>
 struct CholInvSmem {
     union {                            // never live at the same time (barriers in cholinv_attempt separate the uses)
         double Bs[2][64][CI_KC + 2];   // history GEMM: staged chunk of L[C_k rows][kc .. kc+16)
         double Dk[64][66];             // diagonal phase: in D, out L_kk (lower)
-        double St[NW][64][CI_ST];      // panel init / panel store: per-wave 64 x 16 slab that turns row-contiguous
+        double St[NW][16 * UPW][CI_ST];   // panel store: per-wave (16 UPW) x 16 slab that turns row-contiguous
                                        // 16-byte global accesses into the transposed accumulator layout
     };
     double Xk[64][66];             // L_kk^-1 (lower, exact zeros above the diagonal)
@@ -77,7 +74,7 @@ struct CholInvSmem {
     double logdet;
     int fail;
 };
-static_assert(sizeof(CholInvSmem<4>) <= 80 * 1024, "two 4-wave workgroups per CU need <= 80 KB each");
+static_assert(sizeof(CholInvSmem<4, 4>) <= 80 * 1024, "two 4-wave workgroups per CU need <= 80 KB each");
 
 #define CI_S 66   // LDS row stride (doubles) of Dk / Xk
 
@@ -177,7 +174,7 @@ __device__ unsigned long long g_diag_dbg[8];
 // computed TRANSPOSED (lt = X(t,t) D(s,t)^T = L(s,t)^T): lt is at once the A operand L(s,t) and the B operand L(u,t)^T of
 // the trailing update, and the partial sums P of the inverse feed X(s,s) P straight from their accumulators -- no LDS
 // round trips between dependent products, and all LDS reads of a stage are issued before its MFMAs.
-__device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X, double *dv, int *fail, double *logdet, int lane) {
+__device__ __forceinline__ void diag_factor_wave_body(double *D, double *X, double *dv, int *fail, double *logdet, int lane) {
     const int li = lane & 15, g = lane >> 4;
 #define TD(s, t) (D + (16 * (s)) * CI_S + 16 * (t))
 #define TX(s, t) (X + (16 * (s)) * CI_S + 16 * (t))
@@ -291,6 +288,12 @@ __device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X,
 #undef TD
 #undef TX
 }
+// Out of line: bounds the register pressure around the call.  (A 16-wave shape -- 8 waves x 2 units, 128 VGPRs, four waves
+// per SIMD -- was measured at 2.78 ms against 1.66 ms for 4 waves x 4 units at 512 x N=512: the callee does not inherit a
+// smaller register budget, and inlined into 128 VGPRs the kernel spills in every phase.)
+__device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X, double *dv, int *fail, double *logdet, int lane) {
+    diag_factor_wave_body(D, X, dv, fail, logdet, lane);
+}
 
 // ---- one factorisation attempt; returns false if a pivot failed ---------------------------------------------------
 // Split of a step's row blocks over the waves: a pass covers NW block slots (M blocks first, then the U blocks by
@@ -346,10 +349,11 @@ __device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X,
         STAMP(7); /* chunk barrier wait */                                                                         \
     }
 
-template <int NW>
-__device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int want_inv, CholInvSmem<NW> &sm) {
+template <int NW, int UPW>
+__device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int want_inv, CholInvSmem<NW, UPW> &sm) {
     constexpr int NT = NW * 64;
-    constexpr int G = NW / 4;            // wave groups; a pass covers NW block slots
+    constexpr int G = NW / 4;            // wave groups
+    constexpr int BPP = G * UPW;         // 64-row block slots per pass (UPW 16-row units per wave)
     static_assert(NW % 4 == 0, "waves come in groups of four 16-row units");
     const int ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
     gd_t *Lb = (gd_t *)(L.Kmat + (size_t)b * ld * ld);
@@ -379,9 +383,6 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
     const long exp_off = ((long)(b % CI_EXP_ALIAS) - (long)b) * ld * ld;
     const double exp_zero = (L.ldn < 0) ? 1.0 : 0.0;   // opaque zero
 #endif
-#ifdef CI_EXP_KALIAS
-    const double kzero = (L.ldn < 0) ? 1.0 : 0.0;
-#endif
     if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
     __syncthreads();
 #ifdef MEDGP_STAMPS
@@ -393,16 +394,16 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
         const int c0 = 64 * k;                       // first column of the panel
         const int nM = nb - k;                       // K-row blocks (first one is the diagonal block)
         const int ntot = nM + (want_inv ? k : 0);    // + U-row blocks
-        const int npass = (ntot + NW - 1) / NW;
+        const int npass = (ntot + BPP - 1) / BPP;
         const int nch = c0 / CI_KC;                  // history chunks
         for (int pass = 0; pass < npass; pass++) {
             // my four slots (wave-uniform scalars)
-            bool act[4], isM[4];
-            int rowb[4], cf[4];
-            const gd_t *ub[4];
+            bool act[UPW], isM[UPW];
+            int rowb[UPW], cf[UPW];
+            const gd_t *ub[UPW];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int bidx = pass * NW + u * G + wg;
+            for (int u = 0; u < UPW; u++) {
+                const int bidx = pass * BPP + u * G + wg;
                 act[u] = bidx < ntot;
                 isM[u] = bidx < nM;
                 const int rblk = isM[u] ? (k + bidx) : (bidx - nM);
@@ -411,84 +412,24 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 ub[u] = (isM[u] ? Lb : Ub) + (size_t)rowb[u] * ld;
             }
             // first chunk anybody in the workgroup needs: slot 0 of group 0 has the longest history
-            const int bidx0 = pass * NW;
+            const int bidx0 = pass * BPP;
             const int cstart = (bidx0 < nM) ? 0 : (64 * (bidx0 - nM)) / CI_KC;
             // acc starts at -init (init = K block for K rows, 0 for U rows); the history GEMM adds P, so the panel
             // value is  init - P = -acc  (the sign is folded into the operands that consume acc)
-#if CI_SLAB_INIT
-            v4d acc[4][4];
-            {
-                CI_SLAB_LANE();
-                bool ldu[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) ldu[u] = act[u] && isM[u];
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    v2d kin[2][8];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (ldu[u]) {
-                            const gd_t *src = ub[u] + (size_t)srow8 * ld + c0 + 32 * half + 2 * spc;
-#pragma unroll
-                            for (int cth = 0; cth < 2; cth++)
-#pragma unroll
-                                for (int j = 0; j < 2; j++) kin[cth][2 * u + j] = *(const gv2d_t *)(src + (size_t)(8 * j) * ld + 16 * cth);
-                        }
-                    }
-#pragma unroll
-                    for (int cth = 0; cth < 2; cth++) {
-                        const int ct = 2 * half + cth;
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            if (ldu[u]) {
-#pragma unroll
-                                for (int j = 0; j < 2; j++) *(v2d *)&S[16 * u + 8 * j + srow8][2 * spc] = kin[cth][2 * u + j];
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
-                            if (ldu[u]) {
-#pragma unroll
-                                for (int r = 0; r < 4; r++) acc[ct][u][r] = -S[16 * u + (lane_o & 15)][4 * r + (lane_o >> 4)];
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    }
-#ifdef MEDGP_STAMPS
-                    if (half == 0) STAMP(1);
-#endif
-                }
-            }
-#else
-            v4d acc[4][4];
+            // (panel init stays on direct 8-byte loads of the transposed layout: routing it through the LDS slab as well --
+            //  coalesced 16-byte loads, transposition in LDS -- made hipcc spill four accumulator tiles inside the MFMA
+            //  loop: 2.2 ms instead of 1.8 ms at 512 x N=512)
+            v4d acc[4][UPW];
 #pragma unroll
             for (int ct = 0; ct < 4; ct++)
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < UPW; u++) {
                     acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
                     if (act[u] && isM[u]) {
 #pragma unroll
-#ifdef CI_EXP_KALIAS   // diagnostic: off-diagonal K blocks read from batch entry b % CI_EXP_KALIAS, scaled by zero
-                        for (int r = 0; r < 4; r++) {
-                            const bool dg = (pass == 0 && wg == 0 && u == 0);
-                            const long koff = dg ? 0 : ((long)(b % (CI_EXP_KALIAS ? CI_EXP_KALIAS : 1)) - (long)b) * ld * ld;
-#if CI_EXP_KALIAS == 0   // no off-diagonal loads at all
-                            double kv = 0.0;
-                            if (dg) kv = ub[u][(size_t)li * ld + c0 + 16 * ct + 4 * r + g];
-                            (void)koff;
-#else
-                            const double kv = ub[u][koff + (size_t)li * ld + c0 + 16 * ct + 4 * r + g];
-#endif
-                            acc[ct][u][r] = dg ? -kv : kv * kzero;
-                        }
-#else
                         for (int r = 0; r < 4; r++) acc[ct][u][r] = -ub[u][(size_t)li * ld + c0 + 16 * ct + 4 * r + g];
-#endif
                     }
                 }
-#endif
             STAMP(0);   // panel init
             double zsum = 0.0;
             // ---- GEMM over the history, B chunk (L[C_k rows]) staged through LDS, double buffered
@@ -511,12 +452,14 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 // The active set only grows with c (cf ascending), so the loop runs as up to five phases with a fixed
                 // body each (one loop with a switch on the prefix length made hipcc shuffle and spill the accumulators).
                 auto clampc = [&](int v) { return v < cstart ? cstart : (v > nch ? nch : v); };
-                const int p1 = clampc(cf[0]), p2 = clampc(cf[1]), p3 = clampc(cf[2]), p4 = clampc(cf[3]);
-                CI_CHUNK_PHASE(0, cstart, p1)
-                CI_CHUNK_PHASE(1, p1, p2)
-                CI_CHUNK_PHASE(2, p2, p3)
-                CI_CHUNK_PHASE(3, p3, p4)
-                CI_CHUNK_PHASE(4, p4, nch)
+                int pb[5];
+#pragma unroll
+                for (int u = 0; u < 5; u++) pb[u] = (u < UPW) ? clampc(cf[u < UPW ? u : 0]) : nch;
+                CI_CHUNK_PHASE(0, cstart, pb[0])
+                CI_CHUNK_PHASE(1, pb[0], pb[1])
+                if constexpr (UPW >= 2) CI_CHUNK_PHASE(2, pb[1], pb[2])
+                if constexpr (UPW >= 3) CI_CHUNK_PHASE(3, pb[2], pb[3])
+                if constexpr (UPW >= 4) CI_CHUNK_PHASE(4, pb[3], pb[4])
             } else {
                 __syncthreads();   // init slabs done before Dk (same LDS) is written below
             }
@@ -577,26 +520,26 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #if CI_SLAB_STORE
                 CI_SLAB_LANE();
 #endif
-                bool st[4];
+                bool st[UPW];
+                double pal[UPW];
 #pragma unroll
-                for (int u = 0; u < 4; u++) st[u] = act[u] && !(pass == 0 && wg == 0 && u == 0);
-                double pal[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int u = 0; u < UPW; u++) { st[u] = act[u] && !(pass == 0 && wg == 0 && u == 0); pal[u] = 0.0; }
 #pragma unroll
                 for (int ct = 3; ct >= 0; ct--) {
-                    v4d o[4];
+                    v4d o[UPW];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) o[u] = (v4d){0.0, 0.0, 0.0, 0.0};
+                    for (int u = 0; u < UPW; u++) o[u] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int cp = 0; cp <= ct; cp++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             double a = -sm.Xk[16 * ct + li][16 * cp + 4 * r + g];
 #pragma unroll
-                            for (int u = 0; u < 4; u++) o[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[cp][u][r], o[u], 0, 0, 0);
+                            for (int u = 0; u < UPW; u++) o[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[cp][u][r], o[u], 0, 0, 0);
                         }
 #if CI_SLAB_STORE
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < UPW; u++) {
 #pragma unroll
                         for (int r = 0; r < 4; r++) S[16 * u + (lane_o & 15)][4 * r + (lane_o >> 4)] = o[u][r];
                         if (st[u] && !isM[u]) {   // U rows: alpha_i += sum_c U[i][c] z_k[c]
@@ -606,7 +549,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     }
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int i = 0; i < 8; i++) {
+                    for (int i = 0; i < 2 * UPW; i++) {
                         const int u = i >> 1;
                         if (st[u]) {
                             gd_t *Out = (isM[u] ? Lb : Ub) + (size_t)(rowb[u] + 8 * (i & 1) + srow8) * ld + c0 + 16 * ct + 2 * spc;
@@ -619,7 +562,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     __builtin_amdgcn_wave_barrier();
 #else
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < UPW; u++) {
                         if (st[u]) {
                             gd_t *Out = (isM[u] ? Lb : Ub) + (size_t)(rowb[u] + li) * ld + c0 + 16 * ct + g;
 #pragma unroll
@@ -633,7 +576,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #endif
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < UPW; u++) {
                     if (st[u] && !isM[u]) {
                         double v = pal[u];
                         v += __shfl_xor(v, 16);
@@ -662,10 +605,10 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 
 // grid = nbatch, block = NW * 64.  NW = 8: one workgroup per CU (lowest latency per patient);
 // NW = 4: two workgroups per CU, the serial diagonal-block phase of one overlaps the MFMA phase of the other.
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, 2) k_cholinv(MedgpDev L, int want_inv) {
+template <int NW, int UPW>
+__global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int want_inv) {
     constexpr int NT = NW * 64;
-    __shared__ CholInvSmem<NW> sm;
+    __shared__ CholInvSmem<NW, UPW> sm;
     const int b = blockIdx.x, tid = threadIdx.x;
     if (L.status[b] < 0) return;
     // loaded values the whole workgroup agrees on: pin them to scalar registers, otherwise every quantity derived from
@@ -675,7 +618,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_cholinv(MedgpDev L, int want_inv
     const int ld = L.ldn, npad = medgp_roundup(n, 64);
     int count = 0;
     while (true) {
-        if (cholinv_attempt<NW>(L, b, slot, n, want_inv, sm)) break;
+        if (cholinv_attempt<NW, UPW>(L, b, slot, n, want_inv, sm)) break;
         __syncthreads();
         if (count >= 10) {   // ref: c_inference_exact.cpp:99,109-111
             if (tid == 0) L.status[b] = -1;
