@@ -27,7 +27,9 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) double gd_t;
 typedef __attribute__((address_space(1))) v2d gv2d_t;
 
-#define CI_KC 16          // k-columns staged per barrier (32 spills accumulators in the hot loop)
+#ifndef CI_KC
+#define CI_KC 16          // k-columns staged per barrier; the history operand is loaded 16 columns at a time
+#endif
 
 // Diagnostic build only (-DMEDGP_STAMPS, never shipped): per-phase s_memtime sums per wave, written to a debug
 // buffer that no other code reads (guide section 7, "In-kernel stamps").
@@ -315,20 +317,22 @@ __device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X,
 #define CI_CHUNK_PHASE(NA, lo, hi)                                                                                 \
     for (int c = (lo); c < (hi); c++) {                                                                            \
         const int buf = c & 1;                                                                                     \
-        v2d hc[NA > 0 ? NA : 1][CI_KC / 8];                                                                        \
-        _Pragma("unroll") for (int u = 0; u < NA; u++)                                                             \
-            _Pragma("unroll") for (int h = 0; h < CI_KC / 8; h++)                                                  \
-                hc[u][h] = CI_EXP_SCALE(*(const gv2d_t *)(ub[u] + CI_EXP_OFF + loff + c * CI_KC + 8 * h));         \
-        if (c + 1 < nch) {                                                                                         \
-            _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = CI_EXP_SCALE(Bsrc[CI_EXP_OFF + (c + 1) * CI_KC + e]); \
-        }                                                                                                          \
-        if (NA > 0) {                                                                                              \
-            _Pragma("unroll") for (int h = 0; h < CI_KC / 8; h++) {                                                \
-                _Pragma("unroll") for (int ct = 0; ct < 4; ct++) {                                                 \
-                    const v2d a = *(const v2d *)&sm.Bs[buf][16 * ct + li][8 * h + 2 * g];                         \
-                    _Pragma("unroll") for (int s = 0; s < 2; s++)                                                  \
-                        _Pragma("unroll") for (int u = 0; u < NA; u++)                                             \
-                            acc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], hc[u][h][s], acc[ct][u], 0, 0, 0); \
+        _Pragma("unroll") for (int hf = 0; hf < CI_KC / 16; hf++) {                                                \
+            v2d hc[NA > 0 ? NA : 1][2];                                                                            \
+            _Pragma("unroll") for (int u = 0; u < NA; u++)                                                         \
+                _Pragma("unroll") for (int h = 0; h < 2; h++)                                                      \
+                    hc[u][h] = CI_EXP_SCALE(*(const gv2d_t *)(ub[u] + CI_EXP_OFF + loff + c * CI_KC + 16 * hf + 8 * h)); \
+            if (hf == 0 && c + 1 < nch) {                                                                          \
+                _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = CI_EXP_SCALE(Bsrc[CI_EXP_OFF + (c + 1) * CI_KC + e]); \
+            }                                                                                                      \
+            if (NA > 0) {                                                                                          \
+                _Pragma("unroll") for (int h = 0; h < 2; h++) {                                                    \
+                    _Pragma("unroll") for (int ct = 0; ct < 4; ct++) {                                             \
+                        const v2d a = *(const v2d *)&sm.Bs[buf][16 * ct + li][16 * hf + 8 * h + 2 * g];           \
+                        _Pragma("unroll") for (int s = 0; s < 2; s++)                                              \
+                            _Pragma("unroll") for (int u = 0; u < NA; u++)                                         \
+                                acc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], hc[u][h][s], acc[ct][u], 0, 0, 0); \
+                    }                                                                                              \
                 }                                                                                                  \
             }                                                                                                      \
         }                                                                                                          \
