@@ -1,0 +1,38 @@
+"""Regenerate profiles/r01_* from the rocprofv3 outputs of scratch/gpurun_prof.sh <tag> (gpurun_out/prof_<tag>_*)."""
+import csv, glob, collections, json, shutil, sys
+tag = sys.argv[1]
+shutil.copy(glob.glob(f'gpurun_out/prof_{tag}_trace/runc/*_kernel_stats.csv')[0], 'profiles/r01_kernel_stats.csv')
+open('profiles/r01_bench_line_under_rocprof.json', 'w').write([l for l in open(f'gpurun_out/bench_{tag}_trace.log') if l.startswith('{')][-1])
+try:
+    open('profiles/r01_bench_line.json', 'w').write([l for l in open(f'gpurun_out/bench_{tag}_plain.log') if l.startswith('{')][-1])
+except OSError:
+    pass
+out = {}
+for t in ('fetch', 'write', 'mfma', 'sq'):
+    p = glob.glob(f'gpurun_out/prof_{tag}_{t}/runc/*_counter_collection.csv')[0]
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(p)):
+        k = r['Kernel_Name']
+        if k.startswith('__amd'):
+            continue
+        d[k.split('(')[0].replace('void ', '')][r['Counter_Name']].append(float(r['Counter_Value']))
+    for k, v in d.items():
+        out.setdefault(k, {}).update({c: {"mean_per_launch": sum(x) / len(x), "launches": len(x)} for c, x in v.items()})
+for k, v in out.items():
+    if 'FETCH_SIZE' in v:
+        f = v['FETCH_SIZE']['mean_per_launch'] * 1024
+        w = v['WRITE_SIZE']['mean_per_launch'] * 1024
+        v['derived'] = {"fetch_bytes_raw": f, "fetch_bytes_x2_if_wide_loads": 2 * f, "write_bytes": w}
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in v and 'GRBM_GUI_ACTIVE' in v:
+        cyc = v['GRBM_GUI_ACTIVE']['mean_per_launch'] / 8.0
+        v.setdefault('derived', {}).update({
+            "kernel_cycles": cyc,
+            "mfma_busy_frac_of_1024_simds": v['SQ_VALU_MFMA_BUSY_CYCLES']['mean_per_launch'] / (1024 * cyc),
+            "mfma_f64_instructions": v['SQ_INSTS_VALU_MFMA_MOPS_F64']['mean_per_launch'] / 4.0,
+            "valu_wave_instructions": v['SQ_INSTS_VALU']['mean_per_launch'],
+            "valu_issue_frac_of_1024_simds": v['SQ_INSTS_VALU']['mean_per_launch'] * 4 / (1024 * cyc),
+            "wait_any_frac_of_wave_cycles": v['SQ_WAIT_ANY']['mean_per_launch'] / v['SQ_WAVE_CYCLES']['mean_per_launch'] if 'SQ_WAVE_CYCLES' in v else None})
+json.dump(out, open('profiles/r01_pmc_summary.json', 'w'), indent=1)
+for k, v in out.items():
+    print(k, {a: (round(b, 3) if isinstance(b, float) and b < 10 else int(b)) for a, b in v.get('derived', {}).items()})
+print(open('profiles/r01_kernel_stats.csv').read()[:1100])
