@@ -9,7 +9,7 @@
 // turns the K rows into L and the identity rows into U = L^-T (the same recurrence that turns an
 // appended y^T into z^T = (L^-1 y)^T).  Every 64-wide step k therefore updates exactly N rows:
 // (nb - k) blocks of K rows with history length 64k and k blocks of U rows with history 64(k - rho):
-// uniform work per step, one 32 x 64 half block per wave (16 waves), all GEMMs on MFMA.
+// uniform work per step, split over the waves in 16-row units (see cholinv_attempt), all GEMMs on MFMA.
 //
 // Data (row-major, leading dimension ldn):  Kmat: K lower in, L lower out.  Linv: U = L^-T upper out,
 // i.e. (L^-1)[i][j] = U[j][i]; the strictly-lower part of each diagonal 64-block of U is zeroed.
@@ -42,15 +42,9 @@ typedef __attribute__((address_space(1))) v2d gv2d_t;
         st_last = t_;                                                                              \
     } while (0)
 #else
-// Shipped build: a stamp position keeps the SAME instruction (a scalar clock read + lgkmcnt(0), result unused) as a
-// scheduling anchor.  Measured: with these anchors hipcc keeps the accumulator tiles in registers through the MFMA
-// block (2.08 ms); with plain compiler fences or nothing it spills inside the block (2.48 - 2.53 ms, 512 x N=512).
-#define STAMP(idx)                                                                                 \
-    do {                                                                                           \
-        unsigned long long t_;                                                                     \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
-        (void)t_;                                                                                  \
-    } while (0)
+// (An earlier form of the loop needed these positions as scheduling anchors to keep hipcc from spilling inside the MFMA
+//  block; with fixed-body phases and scalar-pinned tables it no longer does -- scratch/hotloop_spills.sh checks the ISA.)
+#define STAMP(idx) do {} while (0)
 #endif
 #ifndef CI_SLAB_STORE
 #define CI_SLAB_STORE 1
@@ -71,7 +65,6 @@ struct CholInvSmem {
     double zk[64];                 // z of the current panel (for the in-step alpha accumulation)
     double zs[1024];               // z history kept in LDS for n <= 1024: the in-loop z product then issues no
                                    // global loads, whose wait (vmcnt) would also drain the operand loads
-    double rdiag[16];              // 1 / diag of the current 16x16 tile
     double red[16];
     double logdet;
     int fail;
