@@ -470,8 +470,13 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
                                                   double *__restrict__ nlml_out, double *__restrict__ grad_out,
                                                   int *__restrict__ status_out) {
     __shared__ double red[256];
+    // LDS copies of S_q (all q) and of A for the Q D R gradients dA_q = S_q A_q (each a D-term dot product whose
+    // operands otherwise come from global memory one dependent pair at a time); used when they fit
+    constexpr int EPI_S_MAX = 4096, EPI_A_MAX = 1280;
+    __shared__ double s_S[EPI_S_MAX], s_A[EPI_A_MAX];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int H = L.H, Q = L.Q, D = L.D, R = L.R, ld = L.ldn;
+    const bool lds_sa = flag_grad && L.kidx == 7 && Q * D * D <= EPI_S_MAX && Q * D * R <= EPI_A_MAX;
     const int st = L.status[b];
     double *g = grad_out ? grad_out + (size_t)b * H : nullptr;
     if (tid == 0 && status_out) status_out[b] = st;
@@ -521,6 +526,11 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
         }
         __syncthreads();
     }
+    if (lds_sa) {
+        for (int i = tid; i < Q * D * D; i += nt) s_S[i] = S[i];   // lower triangles are the ones sym_get reads
+        for (int i = tid; i < Q * D * R; i += nt) s_A[i] = th[D + i];
+        __syncthreads();
+    }
     // the 2Q frequency / length-scale gradients are D(D+1)/2-term contractions  sum B_q o SM_q,  sum B_q o SV_q : one wave
     // each (lanes stride over the bins, fixed butterfly) instead of one thread each -- left to single threads they were
     // the critical path of this kernel (300 dependent load pairs at D = 24 while 246 threads idled)
@@ -560,10 +570,15 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
                     hv = th[h];
                     if (flag_grad) {
                         int q = hc / (D * R), rem = hc - q * D * R, d = rem / R, r = rem - d * R;
-                        const double *A = th + D + (size_t)q * D * R;
-                        const double *Sq = S + (size_t)q * D * D;
                         double s = 0.0;
-                        for (int e = 0; e < D; e++) s += sym_get(Sq, D, d, e) * A[e * R + r];
+                        if (lds_sa) {
+                            const double *A = s_A + q * D * R, *Sq = s_S + q * D * D;
+                            for (int e = 0; e < D; e++) s += sym_get(Sq, D, d, e) * A[e * R + r];
+                        } else {
+                            const double *A = th + D + (size_t)q * D * R;
+                            const double *Sq = S + (size_t)q * D * D;
+                            for (int e = 0; e < D; e++) s += sym_get(Sq, D, d, e) * A[e * R + r];
+                        }
                         gv = s;
                     }
                 } else if (hc < Q * (D * R + 2)) {
