@@ -27,8 +27,9 @@ __device__ __forceinline__ double exp_neg(double x) {
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    int n = (int)fmax(nf, -1100.0);
-    return ldexp(p, n);
+    // v_cvt_i32_f64 saturates, and v_ldexp_f64 flushes exponents below the denormal range to zero, so a hugely negative
+    // nf needs no clamp (arguments here are c_q dt^2 with dt in hours: |nf| stays far inside the int range anyway)
+    return ldexp(p, __double2int_rn(nf));
 }
 
 // value of `v` in lane `srclane` (wave-uniform index) as a scalar: two v_readlane_b32
