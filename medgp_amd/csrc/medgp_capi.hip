@@ -192,9 +192,11 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
     };
     const bool inv = flag_grad || need_inverse;
     // few large patients: one workgroup per 64-row block and two launches per panel (kernels_cholinv_mc.h)
-    // measured on MI355X (D=24): N=512: 64 patients 0.77 vs 1.15 ms, 256 patients 2.7 vs 1.35 ms; N=1024 x 64: 3.7 vs 6.2 ms;
-    // N=2048 x 16: 5.6 vs 38 ms  (multi-CU vs one workgroup per patient)
-    const bool multi_cu = !c->use_v0 && (c->force_mc > 0 || (c->force_mc == 0 && nt64 >= 2 && (nbatch <= c->num_cu / 2 || (nbatch < c->num_cu && nt64 >= 16))));
+    // measured on MI355X (D=24, factorisation ms, multi-CU vs one 8-wave workgroup per patient; scratch/quick_shapes.py):
+    // N=512: 64 patients 0.60 vs 0.84, 128: 0.80 vs 0.89, 192: 1.18 vs 0.93; N=1024: 64: 2.0 vs 4.8, 128: 3.9 vs 4.9,
+    // 200: 6.0 vs 5.1; N=2048: 16: 4.4 vs 32, 64: 11.4 vs 33.5.  The multi-CU time grows linearly with the batch, the
+    // single-workgroup time is flat up to one patient per CU: the crossover sits near 0.6 #CU for every N >= 512.
+    const bool multi_cu = !c->use_v0 && (c->force_mc > 0 || (c->force_mc == 0 && nt64 >= 2 && nbatch <= (c->num_cu * 3) / 5));
     if (c->use_v0) {
         launch_assemble();
         { Launcher l(c, KID_POTRF, stream); hipLaunchKernelGGL(k_potrf_v0, dim3(nbatch), dim3(256), 0, stream, L); }
