@@ -184,21 +184,26 @@ __global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, i
             // flush the running sums of row output mcur (skip padding / initial state)
             if (mcur >= 0) {
                 const int rslot = roff[mcur] + (rg - seg[mcur] / 16);
+                // segmented inclusive scan over the lanes (6 shuffle steps, fixed order): the last lane of every column
+                // segment ends up with the segment sum.  (A serial per-segment loop here cost as many VALU instructions
+                // as the whole pair loop.)  Step-major: one exec-mask region per step covers the adds of all 3 QT values.
+                double fv[3 * QT];
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
+                for (int q = 0; q < QT; q++) { fv[q] = sS[q]; fv[QT + q] = -wq[q] * sM[q]; fv[2 * QT + q] = -2.0 * cq[q] * sV[q]; }
 #pragma unroll
-                    for (int q = 0; q < QT; q++) {
-                        // segmented inclusive scan over the lanes (6 shuffle steps, fixed order): the last lane of
-                        // every column segment ends up with the segment sum.  (A serial per-segment loop here cost as
-                        // many VALU instructions as the whole pair loop.)
-                        double v = (pl == 0) ? sS[q] : (pl == 1 ? -wq[q] * sM[q] : -2.0 * cq[q] * sV[q]);
+                for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                    double up[3 * QT];
 #pragma unroll
-                        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-                            const double up = __shfl_up(v, dlt);
-                            if (lane - dlt >= segstart) v += up;
-                        }
-                        if (seglast && mj >= 0) slab[((size_t)(pl * QT + q) * Rmax + rslot) * Cmax + cslot] = v;
+                    for (int k = 0; k < 3 * QT; k++) up[k] = __shfl_up(fv[k], dlt);
+                    if (lane - dlt >= segstart) {
+#pragma unroll
+                        for (int k = 0; k < 3 * QT; k++) fv[k] += up[k];
                     }
+                }
+                if (seglast && mj >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 3 * QT; k++) slab[((size_t)k * Rmax + rslot) * Cmax + cslot] = fv[k];
+                }
             }
 #pragma unroll
             for (int q = 0; q < QT; q++) { sS[q] = 0.0; sM[q] = 0.0; sV[q] = 0.0; }
