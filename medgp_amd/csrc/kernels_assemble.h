@@ -32,6 +32,33 @@ __device__ __forceinline__ double exp_neg(double x) {
     return ldexp(p, __double2int_rn(nf));
 }
 
+// 2^z for z <= 0, same accuracy as exp_neg.  The pair loops call it with z = (-c_q log2 e) dt^2: the base change is folded
+// into the per-component constant, the reduction  f = z - rint(z)  is one exact subtraction (no Cody-Waite pair), and the
+// polynomial is the Taylor series of 2^f (coefficients ln2^k / k!) -- 16 instructions against 18 for exp_neg(c_q dt^2).
+__device__ __forceinline__ double exp2_nonpos(double z) {
+    const double nf = rint(z);
+    const double f = z - nf;                          // |f| <= 1/2, exact
+    double p = 4.4455382718708116e-10;                // ln2^11 / 11!
+    p = fma(p, f, 7.054911620801123e-09);
+    p = fma(p, f, 1.01780860092397e-07);
+    p = fma(p, f, 1.321548679014431e-06);
+    p = fma(p, f, 1.5252733804059841e-05);
+    p = fma(p, f, 0.0001540353039338161);
+    p = fma(p, f, 0.0013333558146428443);
+    p = fma(p, f, 0.009618129107628477);
+    p = fma(p, f, 0.05550410866482158);
+    p = fma(p, f, 0.24022650695910072);
+    p = fma(p, f, 0.6931471805599453);
+    p = fma(p, f, 1.0);
+    return ldexp(p, __double2int_rn(nf));
+}
+#define MEDGP_LOG2E 1.4426950408889634074
+// pin a value every lane agrees on to a scalar register pair
+__device__ __forceinline__ double uniform_d(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // value of `v` in lane `srclane` (wave-uniform index) as a scalar: two v_readlane_b32
 __device__ __forceinline__ double lane_bcast(double v, int srclane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -57,9 +84,9 @@ __global__ void __launch_bounds__(256) k_assemble_t(MedgpDev L) {
     const int *meta = L.pmeta + (size_t)slot * ld;
     const double *csb = L.cs + (size_t)b * QT * ld, *snb = L.sn + (size_t)b * QT * ld;
     double *K = L.Kmat + (size_t)b * ld * ld;
-    double cq[QT];
+    double cq2n[QT];   // -c_q log2(e): exp(-c_q dt^2) = 2^(cq2n dt^2)
 #pragma unroll
-    for (int q = 0; q < QT; q++) cq[q] = hyp[hyp_off_c(L) + q];
+    for (int q = 0; q < QT; q++) cq2n[q] = uniform_d(-hyp[hyp_off_c(L) + q] * MEDGP_LOG2E);
     const int j = 64 * J + lane;
     const bool jv = j < n;
     const double tj = t[j];
@@ -96,7 +123,7 @@ __global__ void __launch_bounds__(256) k_assemble_t(MedgpDev L) {
 #pragma unroll
             for (int q = 0; q < QT; q++) {
                 const double cd = lane_bcast(r_cs[q], rr) * csj[q] + lane_bcast(r_sn[q], rr) * snj[q];
-                acc += bq[q] * (cd * exp_neg(cq[q] * dd));
+                acc += bq[q] * (cd * exp2_nonpos(cq2n[q] * dd));
             }
             if (i == j) { const double lik = hyp[mj]; acc += lik; for (int r = 0; r < L.jit[b]; r++) acc += lik; }   // ref c_inference_exact.cpp:88-92, :101-104
             v = jv ? acc : 0.0;
