@@ -46,6 +46,9 @@ typedef __attribute__((address_space(1))) v2d gv2d_t;
 //  block; with fixed-body phases and scalar-pinned tables it no longer does -- scratch/hotloop_spills.sh checks the ISA.)
 #define STAMP(idx) do {} while (0)
 #endif
+#ifndef CI_SLAB_INIT
+#define CI_SLAB_INIT 1
+#endif
 #ifndef CI_SLAB_STORE
 #define CI_SLAB_STORE 1
 #endif
@@ -413,9 +416,56 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
             const int cstart = (bidx0 < nM) ? 0 : (64 * (bidx0 - nM)) / CI_KC;
             // acc starts at -init (init = K block for K rows, 0 for U rows); the history GEMM adds P, so the panel
             // value is  init - P = -acc  (the sign is folded into the operands that consume acc)
-            // (panel init stays on direct 8-byte loads of the transposed layout: routing it through the LDS slab as well --
-            //  coalesced 16-byte loads, transposition in LDS -- made hipcc spill four accumulator tiles inside the MFMA
-            //  loop: 2.2 ms instead of 1.8 ms at 512 x N=512)
+            // Panel init through the same per-wave slab as the panel stores: row-contiguous 16-byte loads (8 whole lines per
+            // instruction), transposition in LDS.  The loads must be UNCONDITIONAL inside the block (units without a K
+            // block read slot 0's and discard it): with a branch per unit hipcc spilled four accumulator tiles inside the
+            // MFMA loop (2.2 ms); branch-free the loop is spill free and the kernel gains 3 % over 8-byte loads of the
+            // transposed layout (1.69 -> 1.64 ms at 512 x N=512).
+#if CI_SLAB_INIT
+            v4d acc[4][UPW];
+            {
+                CI_SLAB_LANE();
+                bool ldu[UPW], anyld = false;
+#pragma unroll
+                for (int u = 0; u < UPW; u++) { ldu[u] = act[u] && isM[u]; anyld = anyld || ldu[u]; }
+                if (anyld) {   // branch-free inside: units without a K block read the block of slot 0 and discard it
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        v2d kin[2][2 * UPW];
+#pragma unroll
+                        for (int u = 0; u < UPW; u++) {
+                            const gd_t *src = (ldu[u] ? ub[u] : ub[0]) + (size_t)srow8 * ld + c0 + 32 * half + 2 * spc;
+#pragma unroll
+                            for (int cth = 0; cth < 2; cth++)
+#pragma unroll
+                                for (int j = 0; j < 2; j++) kin[cth][2 * u + j] = *(const gv2d_t *)(src + (size_t)(8 * j) * ld + 16 * cth);
+                        }
+#pragma unroll
+                        for (int cth = 0; cth < 2; cth++) {
+                            const int ct = 2 * half + cth;
+#pragma unroll
+                            for (int u = 0; u < UPW; u++)
+#pragma unroll
+                                for (int j = 0; j < 2; j++) *(v2d *)&S[16 * u + 8 * j + srow8][2 * spc] = kin[cth][2 * u + j];
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int u = 0; u < UPW; u++)
+#pragma unroll
+                                for (int r = 0; r < 4; r++) {
+                                    const double kv = S[16 * u + (lane_o & 15)][4 * r + (lane_o >> 4)];
+                                    acc[ct][u][r] = ldu[u] ? -kv : 0.0;
+                                }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+                        for (int u = 0; u < UPW; u++) acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
+                }
+            }
+#else
             v4d acc[4][UPW];
 #pragma unroll
             for (int ct = 0; ct < 4; ct++)
@@ -427,6 +477,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                         for (int r = 0; r < 4; r++) acc[ct][u][r] = -ub[u][(size_t)li * ld + c0 + 16 * ct + 4 * r + g];
                     }
                 }
+#endif
             STAMP(0);   // panel init
             double zsum = 0.0;
             // ---- GEMM over the history, B chunk (L[C_k rows]) staged through LDS, double buffered
