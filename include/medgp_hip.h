@@ -45,6 +45,14 @@ typedef struct medgp_ctx medgp_ctx;
 #define MEDGP_PRIOR_NORMAL   1
 #define MEDGP_PRIOR_LAPLACE  2
 
+/* flag_grad bits of medgp_nlml_grad / medgp_nlml_grad_device.  The reference passes a bool (`flag_grad`,
+ * ref: inference/c_inference.h:38-52); 0 and 1 keep that meaning.  Bit 1 asks for the factor outputs of the same call
+ * (chol_alpha / chol_factor_inv / beta, ref: inference/c_inference_exact.cpp:124-147) to be formed even when no gradient
+ * is wanted -- GP_Regression::train(false) followed by GP_Regression::predict, ref: core/gp_regression.cpp:102-214,
+ * caller main_one_test.cpp:386-399 -- so that medgp_get_factor is valid afterwards. */
+#define MEDGP_FLAG_GRAD        1
+#define MEDGP_FLAG_KEEP_FACTOR 2
+
 /* ABI version, bumped on any signature change */
 int medgp_abi_version(void);
 
@@ -82,6 +90,14 @@ int medgp_reserve(medgp_ctx *ctx, int max_slots, int max_n, int max_batch);
  * ref: dataio/c_experiment.cpp:272-308), which leaves nlml/gradients unchanged. */
 int medgp_set_patient(medgp_ctx *ctx, int slot, int n, const int32_t *meta, const float *t, const float *y);
 
+/* Packed upload of nslots patients in ONE host-to-device transfer and without waiting for the device: patient k goes to
+ * slots[k] and owns elements [offsets[k], offsets[k+1]) of meta / t / y (offsets has nslots + 1 entries).
+ * Replaces a loop of c_objective_one constructions over a cohort, ref: util/c_objective_one.cpp:23-36, the stacked
+ * per-feature loader arrays of dataio/c_experiment.cpp:254-309, and the per-(time stamp, observation) training subsets
+ * of the imputation loop, ref: main_one_test.cpp:352-365. */
+int medgp_set_patients(medgp_ctx *ctx, int nslots, const int32_t *slots, const int64_t *offsets, const int32_t *meta,
+                       const float *t, const float *y);
+
 /* Per-hyper prior descriptor of one slot, H entries each in theta order; flag == NULL removes the prior.
  * Replaces the public vectors of c_prior read by c_inference_prior::compute_nlml,
  * ref: prior/c_prior.h:35-53, inference/c_inference_prior.cpp:60-150.
@@ -95,6 +111,7 @@ int medgp_set_prior(medgp_ctx *ctx, int slot, const uint8_t *flag, const int32_t
  * ref: util/c_objective_one.cpp:40-82, core/gp_regression.cpp:102-126,
  *      inference/c_inference_prior.cpp:25-154, inference/c_inference_exact.cpp:29-244,
  *      kernel/c_kernel_LMC_SM.cpp:152-327.
+ * flag_grad: 0 = nlml only, MEDGP_FLAG_GRAD = nlml + gradient, | MEDGP_FLAG_KEEP_FACTOR = also keep alpha / L^-1.
  * status[b]: 0..10 = jitter rounds applied (ref: c_inference_exact.cpp:96-111); -1 = the
  * reference's `return false` (Cholesky failed after 10 jitters, or n <= 2,
  * ref: util/c_objective_one.cpp:51,79-81); nlml/grad of a failed problem are NaN.
@@ -107,11 +124,15 @@ int medgp_nlml_grad(medgp_ctx *ctx, int nbatch, const int32_t *slots, const doub
 int medgp_nlml_grad_device(medgp_ctx *ctx, int nbatch, const int32_t *slots, const double *theta_dev,
                            int flag_grad, double *nlml_dev, double *grad_dev, int32_t *status_dev);
 
-/* After medgp_nlml_grad*(…, flag_grad=1): copy out K^-1 (y - m) and L^-1 of batch entry b as the
- * reference's float buffers (alpha[n]; linv[n*n] row-major lower, strict upper zero) in the
- * caller's original observation order when the patient was already grouped by output.
+/* After medgp_nlml_grad*(…, flag_grad with MEDGP_FLAG_GRAD or MEDGP_FLAG_KEEP_FACTOR): copy out K^-1 (y - m), L^-1 and
+ * beta = (y - m)^T K^-1 (y - m) of batch entry b as the reference's float buffers (alpha[n]; linv[n*n] row-major lower,
+ * strict upper zero), ALWAYS in the caller's original observation order -- L^-1 is the inverse Cholesky factor of the
+ * Gram matrix in that order, exactly what GP_Regression::predict multiplies the caller-order cross Gram with
+ * (ref: core/gp_regression.cpp:181-196).  If the entry was evaluated in the internal grouped order (gradient calls on
+ * patients not uploaded grouped by output), asking for linv re-factors that one entry in the caller's order.
+ * Fails (MEDGP_ERR_ARG) when the last call formed no factor (flag_grad == 0, or medgp_fit_predict*).
  * Replaces the chol_alpha / chol_factor_inv / beta outputs of c_inference::compute_nlml,
- * ref: inference/c_inference.h:38-52, inference/c_inference_exact.cpp:124-147. Either pointer may be NULL. */
+ * ref: inference/c_inference.h:38-52, inference/c_inference_exact.cpp:124-147. Any pointer may be NULL. */
 int medgp_get_factor(medgp_ctx *ctx, int b, float *alpha, float *linv, float *beta);
 
 /* Factor once with theta, predict nstar points.  Replaces GP_Regression::train(false) + predict,

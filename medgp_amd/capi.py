@@ -12,6 +12,7 @@ import numpy as np
 
 KERNEL_SE, KERNEL_LMC_SM, KERNEL_SM = 0, 7, 8
 PRIOR_NONE, PRIOR_CLAMP, PRIOR_NORMAL, PRIOR_LAPLACE = -1, 0, 1, 2
+FLAG_GRAD, FLAG_KEEP_FACTOR = 1, 2   # flag_grad bits (include/medgp_hip.h)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -19,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SYMBOLS = [
     "medgp_abi_version", "medgp_device_count", "medgp_create", "medgp_destroy", "medgp_last_error",
     "medgp_num_hyp", "medgp_set_pi", "medgp_set_stream", "medgp_reserve", "medgp_set_patient",
-    "medgp_set_prior", "medgp_nlml_grad", "medgp_nlml_grad_device", "medgp_get_factor",
+    "medgp_set_patients", "medgp_set_prior", "medgp_nlml_grad", "medgp_nlml_grad_device", "medgp_get_factor",
     "medgp_fit_predict", "medgp_fit_predict_batch", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
     "medgp_profile_kernel_name", "medgp_profile_read", "medgp_profile_reset",
 ]
@@ -67,6 +68,7 @@ def load():
     lib.medgp_set_stream.argtypes = [vp, vp]
     lib.medgp_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.medgp_set_patient.argtypes = [vp, C.c_int, C.c_int, i32p, fp, fp]
+    lib.medgp_set_patients.argtypes = [vp, C.c_int, i32p, C.POINTER(C.c_int64), i32p, fp, fp]
     lib.medgp_set_prior.argtypes = [vp, C.c_int, u8p, i32p, u8p, fp, fp]
     lib.medgp_nlml_grad.argtypes = [vp, C.c_int, i32p, dp, C.c_int, dp, dp, i32p]
     lib.medgp_nlml_grad_device.argtypes = [vp, C.c_int, i32p, vp, C.c_int, vp, vp, vp]
@@ -132,6 +134,20 @@ class Context:
         self._chk(self._lib.medgp_set_patient(self._h, int(slot), int(t.shape[0]), _ptr(meta, C.c_int32),
                                               _ptr(t, C.c_float), _ptr(y, C.c_float)))
 
+    def set_patients(self, slots, patients):
+        """Packed upload: patients = list of (meta, t, y); one H2D transfer, no device wait."""
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        ns = [np.asarray(p[1]).shape[0] for p in patients]
+        offsets = np.zeros(len(ns) + 1, dtype=np.int64)
+        offsets[1:] = np.cumsum(ns)
+        t = np.ascontiguousarray(np.concatenate([np.asarray(p[1], dtype=np.float32) for p in patients]), dtype=np.float32)
+        y = np.ascontiguousarray(np.concatenate([np.asarray(p[2], dtype=np.float32) for p in patients]), dtype=np.float32)
+        meta = None
+        if patients[0][0] is not None:
+            meta = np.ascontiguousarray(np.concatenate([np.asarray(p[0], dtype=np.int32) for p in patients]), dtype=np.int32)
+        self._chk(self._lib.medgp_set_patients(self._h, len(ns), _ptr(slots, C.c_int32), offsets.ctypes.data_as(C.POINTER(C.c_int64)),
+                                               _ptr(meta, C.c_int32), _ptr(t, C.c_float), _ptr(y, C.c_float)))
+
     def set_prior(self, slot, flag=None, type=None, is_exp=None, p0=None, p1=None):
         if flag is None:
             self._chk(self._lib.medgp_set_prior(self._h, int(slot), None, None, None, None, None))
@@ -145,8 +161,9 @@ class Context:
         self._chk(self._lib.medgp_set_prior(self._h, int(slot), _ptr(flag, C.c_uint8), _ptr(type, C.c_int32),
                                             _ptr(is_exp, C.c_uint8), _ptr(p0, C.c_float), _ptr(p1, C.c_float)))
 
-    def nlml_grad(self, slots, theta, flag_grad=True):
-        """Host-pointer operator. theta: [nbatch, H]. Returns (nlml[nbatch], grad[nbatch,H] or None, status[nbatch])."""
+    def nlml_grad(self, slots, theta, flag_grad=True, keep_factor=False):
+        """Host-pointer operator. theta: [nbatch, H]. Returns (nlml[nbatch], grad[nbatch,H] or None, status[nbatch]).
+        keep_factor: MEDGP_FLAG_KEEP_FACTOR (alpha / L^-1 available through get_factor even without gradients)."""
         slots = np.ascontiguousarray(slots, dtype=np.int32)
         theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(slots.shape[0], self.H)
         nb = slots.shape[0]
@@ -154,8 +171,8 @@ class Context:
         grad = np.empty((nb, self.H)) if flag_grad else None
         status = np.empty(nb, dtype=np.int32)
         self._chk(self._lib.medgp_nlml_grad(self._h, nb, _ptr(slots, C.c_int32), _ptr(theta, C.c_double),
-                                            int(bool(flag_grad)), _ptr(nlml, C.c_double), _ptr(grad, C.c_double),
-                                            _ptr(status, C.c_int32)))
+                                            int(bool(flag_grad)) | (FLAG_KEEP_FACTOR if keep_factor else 0),
+                                            _ptr(nlml, C.c_double), _ptr(grad, C.c_double), _ptr(status, C.c_int32)))
         return nlml, grad, status
 
     def nlml_grad_device(self, slots, theta_ptr, flag_grad, nlml_ptr, grad_ptr, status_ptr):

@@ -350,7 +350,11 @@ __device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X,
     }
 
 template <int NW, int UPW>
-__device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int want_inv, CholInvSmem<NW, UPW> &sm) {
+__device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int want_mode, CholInvSmem<NW, UPW> &sm) {
+    // want_mode bit 0: U rows + alpha (full inverse); bit 1: only the diagonal blocks U_kk = L_kk^-T are stored (what the
+    // predictive solve k_predict needs)
+    const int want_inv = want_mode & 1;
+    const bool store_ukk = want_mode != 0;
     constexpr int NT = NW * 64;
     constexpr int G = NW / 4;            // wave groups
     constexpr int BPP = G * UPW;         // 64-row block slots per pass (UPW 16-row units per wave)
@@ -554,7 +558,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 for (int e = tid; e < 64 * 64; e += NT) {
                     int rr = e >> 6, cc = e & 63;
                     if (cc <= rr) Lb[(size_t)(c0 + rr) * ld + c0 + cc] = sm.Dk[rr][cc];
-                    if (want_inv) Ub[(size_t)(c0 + rr) * ld + c0 + cc] = (cc >= rr) ? sm.Xk[cc][rr] : 0.0;
+                    if (store_ukk) Ub[(size_t)(c0 + rr) * ld + c0 + cc] = (cc >= rr) ? sm.Xk[cc][rr] : 0.0;
                 }
                 // Dk fully read before the store slabs (same LDS) are written: LDS-only barrier (no wait for the global
                 // stores above, which nobody reads before the next step)
@@ -666,7 +670,7 @@ __global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int wa
     const int ld = L.ldn, npad = medgp_roundup(n, 64);
     int count = 0;
     while (true) {
-        if (cholinv_attempt<NW, UPW>(L, b, slot, n, want_inv, sm)) break;
+        if (cholinv_attempt<NW, UPW>(L, b, slot, n, want_inv, sm) && count >= L.dbg_fail) break;
         __syncthreads();
         if (count >= 10) {   // ref: c_inference_exact.cpp:99,109-111
             if (tid == 0) L.status[b] = -1;

@@ -34,8 +34,9 @@ __device__ inline void mc_diag_factor(McSmem &sm, int lane) {
 }
 
 // grid = (nbatch, max blocks), block = 256 (4 waves x 16 rows)
-__global__ void __launch_bounds__(MC_THREADS) k_ci_panel(MedgpDev L, int k, int want_inv) {
+__global__ void __launch_bounds__(MC_THREADS) k_ci_panel(MedgpDev L, int k, int want_mode) {
     __shared__ McSmem sm;
+    const int want_inv = want_mode & 1;   // bit 1 alone: only the diagonal blocks U_kk are stored (k_predict)
     // grid = (nbatch, blocks): block-slot major, so the diagonal-block workgroups of ALL patients (slot 0: GEMM + the
     // serial 64x64 factorisation, the long pole of the launch) are dispatched first and the history-only workgroups fill
     // in behind them by decreasing history length
@@ -157,14 +158,15 @@ __global__ void __launch_bounds__(MC_THREADS) k_ci_panel(MedgpDev L, int k, int 
     for (int e = tid; e < 64 * 64; e += MC_THREADS) {
         int rr = e >> 6, cc = e & 63;
         if (cc <= rr) Lb[(size_t)(c0 + rr) * ld + c0 + cc] = sm.Dk[rr][cc];
-        if (want_inv) Ub[(size_t)(c0 + rr) * ld + c0 + cc] = (cc >= rr) ? sm.Xk[cc][rr] : 0.0;
+        if (want_mode) Ub[(size_t)(c0 + rr) * ld + c0 + cc] = (cc >= rr) ? sm.Xk[cc][rr] : 0.0;
         Xg[e] = sm.Xk[rr][cc];
     }
 }
 
 // grid = (max blocks - 1, nbatch): every block of step k except the diagonal one
-__global__ void __launch_bounds__(MC_THREADS) k_ci_trsm(MedgpDev L, int k, int want_inv) {
+__global__ void __launch_bounds__(MC_THREADS) k_ci_trsm(MedgpDev L, int k, int want_mode) {
     __shared__ double Xs[64][66];
+    const int want_inv = want_mode & 1;
     const int b = blockIdx.y;
     if (L.status[b] < 0) return;
     const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;

@@ -28,7 +28,10 @@ __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restri
         L.scal[b * 4 + 1] = 0.0;
         L.jit[b] = 0;
     }
-    if (L.kidx == 7) {
+    if (theta == nullptr) {
+        // tables only: the hyper block of this entry is kept (medgp_get_factor re-factors an entry in the caller's
+        // observation order; sigma^2, B_q, w_q, c_q do not depend on the order, the cos / sin tables do)
+    } else if (L.kidx == 7) {
         for (int d = tid; d < D; d += nt) { double s = exp(th[d]); sig2[d] = s * s; }
         const double *A = th + D, *lk = th + D + Q * (D * R + 2);
         for (int idx = tid; idx < Q * D * D; idx += nt) {
@@ -552,7 +555,9 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
         }
         __syncthreads();
     }
-    const MedgpPrior *pr = L.prior_on[slot] ? L.prior + (size_t)slot * H : nullptr;
+    // a caller-order copy of a patient (slot + max_slots, nlml-only evaluations) shares the prior of its patient
+    const int pslot = slot >= L.max_slots ? slot - L.max_slots : slot;
+    const MedgpPrior *pr = L.prior_on[pslot] ? L.prior + (size_t)pslot * H : nullptr;
     double lp_local = 0.0;
     for (int h = tid; h < H; h += nt) {
         double gv = 0.0, hv;   // hv = transformed hyper value (what the prior is evaluated at)
@@ -641,64 +646,5 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
         double logdet = L.scal[b * 4 + 0], quad = L.scal[b * 4 + 1];
         double nlml = quad / 2.0 + logdet + n * log(2. * L.pi) / 2.0;   // ref: c_inference_exact.cpp:149-152
         nlml_out[b] = nlml - red[0];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// predict: one workgroup per test point.  mean = k*^T alpha; var = k** - |L^-1 k*|^2 + sigma^2
-//   ref: core/gp_regression.cpp:128-214, c_kernel_LMC_SM.cpp:329-372, :122-150
-// ------------------------------------------------------------------------------------------
-// grid = (nstar, nbatch): test point js of problem b lives at index b * nstar + js of meta2 / t2 / mean / var
-__global__ void __launch_bounds__(256) k_predict_v0(MedgpDev L, int nstar, const int *__restrict__ meta2,
-                                                   const double *__restrict__ t2, double *__restrict__ ks_buf,
-                                                   float *__restrict__ mean, float *__restrict__ var) {
-    __shared__ double red[256];
-    const int b = blockIdx.y, js = b * nstar + blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, Q = L.Q, D = L.D;
-    if (L.status[b] < 0) {
-        if (tid == 0) { mean[js] = __builtin_nanf(""); var[js] = __builtin_nanf(""); }
-        return;
-    }
-    const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
-    const double *B = hyp + hyp_off_B(L), *w = hyp + hyp_off_w(L), *c = hyp + hyp_off_c(L);
-    const double *t = L.pt + (size_t)slot * ld;
-    const int *meta = L.pmeta + (size_t)slot * ld;
-    const double *alpha = L.alpha + (size_t)b * ld;
-    const double *X = L.Linv + (size_t)b * ld * ld;
-    double *ks = ks_buf + (size_t)js * ld;
-    const int ms = meta2 ? meta2[js] : 0;
-    const double ts = t2[js];
-    double m = 0.0;
-    for (int i = tid; i < n; i += nt) {
-        double d = t[i] - ts, dd = d * d, acc = 0.0;
-        for (int q = 0; q < Q; q++) acc += B[q * D * D + meta[i] * D + ms] * (cos(w[q] * d) * exp(-c[q] * dd));
-        ks[i] = acc;
-        m += acc * alpha[i];
-    }
-    red[tid] = m;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) red[tid] += red[tid + off];
-        __syncthreads();
-    }
-    const double mval = red[0];
-    __syncthreads();
-    double qv = 0.0;
-    for (int i = tid; i < n; i += nt) {   // v_i = sum_{k<=i} (L^-1)[i][k] k*_k, (L^-1)[i][k] = U[k][i]
-        double s = 0.0;
-        for (int k = 0; k <= i; k++) s += X[(size_t)k * ld + i] * ks[k];
-        qv += s * s;
-    }
-    red[tid] = qv;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) red[tid] += red[tid + off];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        double kss = 0.0;
-        for (int q = 0; q < Q; q++) kss += B[q * D * D + ms * D + ms];
-        mean[js] = (float)mval;
-        var[js] = (float)(kss - red[0] + hyp[ms]);
     }
 }

@@ -8,6 +8,7 @@
 #include "kernels_cholinv_mc.h"
 #include "kernels_assemble.h"
 #include "kernels_wgrad.h"
+#include "kernels_io.h"
 
 #include <algorithm>
 #include <cmath>
@@ -23,7 +24,7 @@ namespace {
 enum KernelId { KID_PREP = 0, KID_ASSEMBLE, KID_POTRF, KID_TRTRI, KID_CHOLINV, KID_CI_PANEL, KID_CI_TRSM, KID_LAUUM, KID_GRADBINS, KID_WGRAD, KID_EPILOGUE, KID_PREDICT, KID_COUNT };
 const char *const kKernelNames[KID_COUNT] = {"k_prep", "k_assemble", "k_potrf", "k_trtri", "k_cholinv", "k_ci_panel", "k_ci_trsm", "k_lauum", "k_gradbins", "k_wgrad", "k_epilogue", "k_predict"};
 
-std::string g_create_error;
+thread_local std::string g_create_error;   // last medgp_create error of the calling thread
 
 struct EvPair { int kid; hipEvent_t a, b; };
 
@@ -51,6 +52,13 @@ struct medgp_ctx {
     std::vector<uint8_t> h_perm_identity;
     std::vector<int> h_bslot;
     int last_nbatch = 0;
+    bool last_has_inverse = false;   // the last pipeline run formed alpha and U = L^-T (medgp_get_factor is valid)
+    // upload staging (one pinned host buffer + one device buffer, reused; guarded by ev_stage)
+    char *h_stage = nullptr, *d_stage = nullptr;
+    size_t stage_cap = 0;
+    hipEvent_t ev_stage = nullptr;
+    bool stage_pending = false;
+    int *d_one_slot = nullptr;       // single-entry slot table for the caller-order re-factorisation of medgp_get_factor
     // predict scratch
     double *d_t2 = nullptr, *d_ks = nullptr;
     int *d_meta2 = nullptr;
@@ -62,6 +70,7 @@ struct medgp_ctx {
     int cholinv_nw = 0;       // MEDGP_CHOLINV_NW=44|84 forces the workgroup shape (0 = auto)
     int force_mc = 0;         // MEDGP_MULTI_CU=1 forces / -1 forbids the multi-CU factorisation (0 = auto)
     int num_cu = 256;
+    int dbg_fail = 0;         // MEDGP_DEBUG_FAIL_ATTEMPTS=k: test hook, see MedgpDev::dbg_fail
     int nsplit = 1;           // MEDGP_STREAMS=2 splits large batches over two streams (measured: 98.9k vs 104.6k evals/s -> off)
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
@@ -149,18 +158,23 @@ int drain_events(medgp_ctx *c) {
     return MEDGP_OK;
 }
 
-int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out) {
+// Select the batch.  caller_order: entries whose patient was not uploaded grouped by output use the caller-order copy of
+// the patient (slot + max_slots), so that the factor is the one the caller's order defines (no gradient on that copy).
+int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bool caller_order = false) {
     if (nbatch < 1 || nbatch > c->max_batch) return fail(c, MEDGP_ERR_CAPACITY, "nbatch %d outside [1, %d]", nbatch, c->max_batch);
     int mx = 0;
+    std::vector<int> eff(nbatch);
     for (int b = 0; b < nbatch; b++) {
         int s = slots[b];
         if (s < 0 || s >= c->max_slots || c->h_n[s] < 0) return fail(c, MEDGP_ERR_ARG, "slots[%d] = %d is not a resident patient", b, s);
         mx = std::max(mx, c->h_n[s]);
+        eff[b] = (caller_order && !c->h_perm_identity[s]) ? s + c->max_slots : s;
     }
     *max_n_out = mx;
-    bool same = (nbatch == c->last_nbatch) && std::memcmp(c->h_bslot.data(), slots, sizeof(int) * nbatch) == 0;
+    bool same = (nbatch == c->last_nbatch) && std::memcmp(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch) == 0;
     if (!same) {
-        std::memcpy(c->h_bslot.data(), slots, sizeof(int) * nbatch);
+        std::memcpy(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch);
+        // pageable source: the copy into the runtime's staging buffer is complete when the call returns
         HIPCHK(c, hipMemcpyAsync(c->d_bslot, c->h_bslot.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));   // h_bslot may be rewritten by the next call
         c->last_nbatch = nbatch;
@@ -172,7 +186,8 @@ inline int tri(int n) { return n * (n + 1) / 2; }
 
 // one kernel chain for the batch entries described by L (possibly a shifted view of c->dev) on `stream`
 int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nbatch, int max_n, const double *theta_dev,
-                     int flag_grad, bool need_inverse, int min_n, double *nlml_dev, double *grad_dev, int32_t *status_dev) {
+                     int flag_grad, bool need_inverse, int min_n, double *nlml_dev, double *grad_dev, int32_t *status_dev,
+                     bool store_ukk = false) {
     const int nt64 = medgp_roundup(std::max(max_n, 1), 64) / 64;
     { Launcher l(c, KID_PREP, stream); hipLaunchKernelGGL(k_prep, dim3(nbatch), dim3(256), 0, stream, L, theta_dev, min_n); }
     auto launch_assemble = [&]() {
@@ -191,6 +206,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         }
     };
     const bool inv = flag_grad || need_inverse;
+    const int want_mode = inv ? 1 : (store_ukk ? 2 : 0);   // bit 0: U rows + alpha; 2: diagonal blocks U_kk only (k_predict)
     // few large patients: one workgroup per 64-row block and two launches per panel (kernels_cholinv_mc.h)
     // measured on MI355X (D=24, factorisation ms, multi-CU vs one 8-wave workgroup per patient; scratch/quick_shapes.py):
     // N=512: 64 patients 0.60 vs 0.84, 128: 0.80 vs 0.89, 192: 1.18 vs 0.93; N=1024: 64: 2.0 vs 4.8, 128: 3.9 vs 4.9,
@@ -200,45 +216,41 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
     if (c->use_v0) {
         launch_assemble();
         { Launcher l(c, KID_POTRF, stream); hipLaunchKernelGGL(k_potrf_v0, dim3(nbatch), dim3(256), 0, stream, L); }
-        if (inv) { Launcher l(c, KID_TRTRI, stream); hipLaunchKernelGGL(k_trtri_v0, dim3(nbatch), dim3(256), 0, stream, L); }
+        if (want_mode) { Launcher l(c, KID_TRTRI, stream); hipLaunchKernelGGL(k_trtri_v0, dim3(nbatch), dim3(256), 0, stream, L); }
     } else if (multi_cu) {
-        std::vector<int> hst(nbatch), hjit(nbatch, 0);
+        // The reference's retry loop (c_inference_exact.cpp:99-111: add the noise vector again, at most 10 times) is driven
+        // from the host here: a failed pivot leaves status -2; the failed problems restart with one more noise addition
+        // (L.jit), finished ones are recomputed identically (same inputs, same order of operations).
+        std::vector<int> hst(nbatch), hjit(nbatch, 0), nst(nbatch);
         for (int attempt = 0;; attempt++) {
             launch_assemble();
             for (int k = 0; k < nt64; k++) {
-                { Launcher l(c, KID_CI_PANEL, stream); hipLaunchKernelGGL(k_ci_panel, dim3(nbatch, nt64), dim3(MC_THREADS), 0, stream, L, k, inv ? 1 : 0); }
-                if (nt64 > 1) { Launcher l(c, KID_CI_TRSM, stream); hipLaunchKernelGGL(k_ci_trsm, dim3(nt64 - 1, nbatch), dim3(MC_THREADS), 0, stream, L, k, inv ? 1 : 0); }
+                { Launcher l(c, KID_CI_PANEL, stream); hipLaunchKernelGGL(k_ci_panel, dim3(nbatch, nt64), dim3(MC_THREADS), 0, stream, L, k, want_mode); }
+                if (nt64 > 1) { Launcher l(c, KID_CI_TRSM, stream); hipLaunchKernelGGL(k_ci_trsm, dim3(nt64 - 1, nbatch), dim3(MC_THREADS), 0, stream, L, k, want_mode); }
             }
             hipLaunchKernelGGL(k_ci_finish, dim3(nbatch), dim3(256), 0, stream, L);
             HIPCHK(c, hipMemcpyAsync(hst.data(), L.status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, stream));
             HIPCHK(c, hipStreamSynchronize(stream));
-            bool retry = false;
-            for (int bb = 0; bb < nbatch; bb++)
-                if (hst[bb] == -2) {   // ref c_inference_exact.cpp:99-111: add the noise again, at most 10 times
-                    if (hjit[bb] >= 10) hst[bb] = -1;
-                    else { hjit[bb]++; hst[bb] = 0; retry = true; }
-                } else if (hst[bb] >= 0) hst[bb] = 0;
+            if (attempt < c->dbg_fail)   // test hook: this attempt counts as failed for every live problem
+                for (int bb = 0; bb < nbatch; bb++) if (hst[bb] >= 0) hst[bb] = -2;
+            bool retry = false, rewrite = false;
+            for (int bb = 0; bb < nbatch; bb++) {
+                if (hst[bb] == -2) {
+                    if (hjit[bb] >= 10) { nst[bb] = -1; rewrite = true; }       // the reference's `return false`
+                    else { hjit[bb]++; nst[bb] = 0; retry = true; }
+                } else nst[bb] = hst[bb];                                       // -1 (n below the guard) or the jitter count
+            }
             if (!retry) {
-                bool fix = false;
-                for (int bb = 0; bb < nbatch; bb++) fix = fix || (hjit[bb] >= 10 && hst[bb] == -1);
-                if (fix) {   // final failures: publish -1
-                    std::vector<int> cur(nbatch);
-                    HIPCHK(c, hipMemcpy(cur.data(), L.status, sizeof(int) * nbatch, hipMemcpyDeviceToHost));
-                    for (int bb = 0; bb < nbatch; bb++) if (cur[bb] == -2) cur[bb] = -1;
-                    HIPCHK(c, hipMemcpy(L.status, cur.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice));
-                }
+                if (rewrite) HIPCHK(c, hipMemcpyAsync(L.status, nst.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, stream));
+                if (rewrite) HIPCHK(c, hipStreamSynchronize(stream));
                 break;
             }
-            // failed problems restart with one more noise addition; finished ones are recomputed identically
-            std::vector<int> cur(nbatch);
-            HIPCHK(c, hipMemcpy(cur.data(), L.status, sizeof(int) * nbatch, hipMemcpyDeviceToHost));
-            for (int bb = 0; bb < nbatch; bb++) if (cur[bb] == -2 || cur[bb] >= 0) cur[bb] = (hst[bb] == -1) ? -1 : 0;
-            HIPCHK(c, hipMemcpy(L.status, cur.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice));
-            HIPCHK(c, hipMemcpy(L.jit, hjit.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice));
-            // logdet accumulators restart
-            std::vector<double> zero4(4 * (size_t)nbatch, 0.0);
-            HIPCHK(c, hipMemcpy(L.scal, zero4.data(), sizeof(double) * 4 * nbatch, hipMemcpyHostToDevice));
-            (void)attempt;
+            for (int bb = 0; bb < nbatch; bb++) if (nst[bb] > 0) nst[bb] = 0;   // live again: k_ci_finish re-publishes the count
+            std::vector<double> zero4(4 * (size_t)nbatch, 0.0);                 // log-det accumulators restart
+            HIPCHK(c, hipMemcpyAsync(L.status, nst.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, stream));
+            HIPCHK(c, hipMemcpyAsync(L.jit, hjit.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, stream));
+            HIPCHK(c, hipMemcpyAsync(L.scal, zero4.data(), sizeof(double) * 4 * nbatch, hipMemcpyHostToDevice, stream));
+            HIPCHK(c, hipStreamSynchronize(stream));
         }
     } else {
         launch_assemble();
@@ -246,8 +258,8 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         // more patients than CUs: 4-wave workgroups, two per CU (the serial diagonal phase of one overlaps the
         // MFMA phase of the other); else 8 waves for the lowest latency per patient
         const int shape = c->cholinv_nw ? c->cholinv_nw : (nbatch > c->num_cu ? 44 : 84);
-        if (shape == 44) hipLaunchKernelGGL((k_cholinv<4, 4>), dim3(nbatch), dim3(256), 0, stream, L, inv ? 1 : 0);
-        else hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, inv ? 1 : 0);
+        if (shape == 44) hipLaunchKernelGGL((k_cholinv<4, 4>), dim3(nbatch), dim3(256), 0, stream, L, want_mode);
+        else hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, want_mode);
     }
     int from_slab = 0;
 #ifdef MEDGP_STAMPS
@@ -304,9 +316,10 @@ MedgpDev shifted_view(const MedgpDev &L, int b0) {
 // in two halves on two auxiliary streams so that k_cholinv of one half co-runs with the VALU-heavy kernels of the
 // other half.  Measured on MI355X at the headline shape: no gain (98.9k vs 104.6k evals/s), so it is off by default.
 int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, int flag_grad, bool need_inverse, int min_n,
-                 double *nlml_dev, double *grad_dev, int32_t *status_dev) {
+                 double *nlml_dev, double *grad_dev, int32_t *status_dev, bool store_ukk = false) {
+    c->last_has_inverse = flag_grad || need_inverse;
     const bool split = !c->use_v0 && c->nsplit >= 2 && nbatch >= 2 * c->num_cu && c->aux[0] && c->aux[1];
-    if (!split) return run_pipeline_one(c, c->stream, c->dev, nbatch, max_n, theta_dev, flag_grad, need_inverse, min_n, nlml_dev, grad_dev, status_dev);
+    if (!split) return run_pipeline_one(c, c->stream, c->dev, nbatch, max_n, theta_dev, flag_grad, need_inverse, min_n, nlml_dev, grad_dev, status_dev, store_ukk);
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     const int h = (nbatch / 2 + 1) & ~1;   // even: keeps the (b & 1) wave mirroring of k_cholinv consistent
     const int b0[2] = {0, h}, nb[2] = {h, nbatch - h};
@@ -315,7 +328,7 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
         MedgpDev V = shifted_view(c->dev, b0[i]);
         int rc = run_pipeline_one(c, c->aux[i], V, nb[i], max_n, theta_dev + (size_t)b0[i] * c->H, flag_grad, need_inverse, min_n,
                                   nlml_dev ? nlml_dev + b0[i] : nullptr, grad_dev ? grad_dev + (size_t)b0[i] * c->H : nullptr,
-                                  status_dev ? status_dev + b0[i] : nullptr);
+                                  status_dev ? status_dev + b0[i] : nullptr, store_ukk);
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(c->ev_join[i], c->aux[i]));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
@@ -327,7 +340,7 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
 
 extern "C" {
 
-int medgp_abi_version(void) { return 1; }
+int medgp_abi_version(void) { return 2; }
 
 int medgp_device_count(void) {
     int n = 0;
@@ -363,6 +376,7 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     { const char *e = getenv("MEDGP_CHOLINV_NW"); c->cholinv_nw = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_MULTI_CU"); c->force_mc = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_STREAMS"); c->nsplit = e ? atoi(e) : 1; }
+    { const char *e = getenv("MEDGP_DEBUG_FAIL_ATTEMPTS"); c->dbg_fail = e ? atoi(e) : 0; }
     for (int i = 0; i < 2; i++) {
         (void)hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
         (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
@@ -384,6 +398,8 @@ void medgp_destroy(medgp_ctx *c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -425,13 +441,16 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     c->ldn = ldn;
     const size_t S = max_slots, B = max_batch, Q = c->Q, D = c->D, H = c->H;
     int rc;
-    if ((rc = dalloc(c, &c->d_pn, S))) return rc;
-    if ((rc = dalloc(c, &c->d_pt, S * ldn))) return rc;
-    if ((rc = dalloc(c, &c->d_py, S * ldn))) return rc;
-    if ((rc = dalloc(c, &c->d_pmeta, S * ldn))) return rc;
-    if ((rc = dalloc(c, &c->d_pseg, S * (D + 1)))) return rc;
-    if ((rc = dalloc(c, &c->d_proff, S * (D + 1)))) return rc;
-    if ((rc = dalloc(c, &c->d_pcoff, S * (D + 1)))) return rc;
+    // patient rows: [0, S) grouped by output (what the gradient kernels need); [S, 2S) the same patient in the CALLER's
+    // observation order, filled only when that order is not already grouped (used for caller-order factors)
+    if ((rc = dalloc(c, &c->d_pn, 2 * S))) return rc;
+    if ((rc = dalloc(c, &c->d_pt, 2 * S * ldn))) return rc;
+    if ((rc = dalloc(c, &c->d_py, 2 * S * ldn))) return rc;
+    if ((rc = dalloc(c, &c->d_pmeta, 2 * S * ldn))) return rc;
+    if ((rc = dalloc(c, &c->d_pseg, 2 * S * (D + 1)))) return rc;
+    if ((rc = dalloc(c, &c->d_proff, 2 * S * (D + 1)))) return rc;
+    if ((rc = dalloc(c, &c->d_pcoff, 2 * S * (D + 1)))) return rc;
+    if ((rc = dalloc(c, &c->d_one_slot, 1))) return rc;
     if ((rc = dalloc(c, &c->d_prior, S * H))) return rc;
     if ((rc = dalloc(c, &c->d_prior_on, S))) return rc;
     if ((rc = dalloc(c, &c->d_bslot, B))) return rc;
@@ -446,6 +465,7 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     L.ldn = ldn; L.max_slots = max_slots; L.max_batch = max_batch;
     L.hyp_stride = (int)(D + Q * D * D + 2 * Q);
     L.pi = c->pi;
+    L.dbg_fail = c->dbg_fail;
     double *hyp, *cs, *sn, *Kmat, *Linv, *z, *alpha, *scal, *Sb, *SMb, *SVb, *slab, *wdiag;
     L.slab_R = ldn / 16 + (int)D;
     L.slab_C = ldn / 64 + (int)D;
@@ -472,69 +492,148 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     L.hyp = hyp; L.cs = cs; L.sn = sn; L.Kmat = Kmat; L.Linv = Linv; L.z = z; L.alpha = alpha; L.scal = scal;
     L.status = c->d_status; L.S = Sb; L.SM = SMb; L.SV = SVb;
     HIPCHK(c, hipMemsetAsync(c->d_prior_on, 0, S, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_pn, 0, S * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_pn, 0, 2 * S * sizeof(int), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->h_n.assign(max_slots, -1);
     c->h_perm.assign(max_slots, {});
     c->h_perm_identity.assign(max_slots, 1);
     c->h_bslot.assign(max_batch, -1);
     c->last_nbatch = 0;
+    c->last_has_inverse = false;
     c->pred_cap = 0;
+    c->d_stage = nullptr;   // freed by free_all above
+    if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; }
+    c->stage_cap = 0;
+    c->stage_pending = false;
     return MEDGP_OK;
 }
+
+// ---- patient upload: any number of patients are packed into one pinned staging buffer, copied with ONE H2D transfer and
+// scattered into their padded slot rows by k_scatter_patients; nothing waits for the device (the staging buffer is
+// guarded by an event that is only waited for when the next upload starts).
+namespace {
+struct UpEntry { int slot, n; const int32_t *meta; const float *t, *y; };
+
+inline size_t up_payload_bytes(int n, int D) { return ((size_t)n * 20 + (size_t)(D + 1) * 12 + 7) & ~(size_t)7; }
+
+int upload_patients(medgp_ctx *c, const std::vector<UpEntry> &ents) {
+    const int D = c->D, S = c->max_slots, ldn = c->ldn;
+    const bool use_meta = (c->kidx == MEDGP_KERNEL_LMC_SM);
+    // validate everything before touching any state
+    for (const UpEntry &e : ents) {
+        if (e.slot < 0 || e.slot >= S) return fail(c, MEDGP_ERR_CAPACITY, "slot %d outside [0, %d)", e.slot, S);
+        if (e.n < 0 || e.n > c->max_n) return fail(c, MEDGP_ERR_CAPACITY, "n = %d outside [0, %d]", e.n, c->max_n);
+        if (e.n > 0 && (!e.t || !e.y)) return fail(c, MEDGP_ERR_ARG, "t / y is NULL");
+        if (use_meta && e.n > 0 && !e.meta) return fail(c, MEDGP_ERR_ARG, "meta is NULL for the multi-output kernel");
+        if (use_meta)
+            for (int i = 0; i < e.n; i++)
+                if (e.meta[i] < 0 || e.meta[i] >= D) return fail(c, MEDGP_ERR_ARG, "meta[%d] = %d outside [0, %d)", i, e.meta[i], D);
+    }
+    // worst case: every patient also needs its caller-order copy
+    size_t bytes = 0;
+    for (const UpEntry &e : ents) bytes += 2 * (sizeof(MedgpUpHdr) + up_payload_bytes(e.n, D));
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->stage_pending) { HIPCHK(c, hipEventSynchronize(c->ev_stage)); c->stage_pending = false; }
+    if (bytes > c->stage_cap) {
+        const size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_stage, cap, hipHostMallocDefault));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // the old device buffer may still be read by a queued scatter
+        if (c->d_stage) {
+            (void)hipFree(c->d_stage);
+            c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), (void *)c->d_stage), c->allocs.end());
+            c->d_stage = nullptr;
+        }
+        int rc = dalloc(c, &c->d_stage, cap);
+        if (rc) return rc;
+        c->stage_cap = cap;
+    }
+    if (!c->ev_stage) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
+    // count the device entries (grouped copy of every patient + caller-order copy of the ungrouped ones)
+    std::vector<std::vector<int>> perms(ents.size());
+    std::vector<uint8_t> ident(ents.size(), 1);
+    int nent = 0;
+    for (size_t k = 0; k < ents.size(); k++) {
+        const UpEntry &e = ents[k];
+        std::vector<int> &perm = perms[k];
+        perm.resize(e.n);
+        if (use_meta) {   // stable grouping by output (counting sort)
+            std::vector<int> pos(D + 1, 0);
+            for (int i = 0; i < e.n; i++) pos[e.meta[i] + 1]++;
+            for (int d = 0; d < D; d++) pos[d + 1] += pos[d];
+            for (int i = 0; i < e.n; i++) perm[pos[e.meta[i]]++] = i;
+        } else {
+            for (int i = 0; i < e.n; i++) perm[i] = i;
+        }
+        for (int i = 0; i < e.n; i++) if (perm[i] != i) { ident[k] = 0; break; }
+        nent += ident[k] ? 1 : 2;
+    }
+    MedgpUpHdr *hdr = (MedgpUpHdr *)c->h_stage;
+    size_t off = (size_t)nent * sizeof(MedgpUpHdr);
+    int ie = 0;
+    auto pack = [&](const UpEntry &e, int dev_slot, const int *perm) {
+        hdr[ie].slot = dev_slot; hdr[ie].n = e.n; hdr[ie].off = (long long)off; ie++;
+        double *pt = (double *)(c->h_stage + off), *py = pt + e.n;
+        int *pm = (int *)(py + e.n), *seg = pm + e.n, *roff = seg + (D + 1), *coff = roff + (D + 1);
+        for (int i = 0; i < e.n; i++) {
+            const int src = perm ? perm[i] : i;
+            pt[i] = (double)e.t[src];
+            py[i] = (double)e.y[src];   // zero mean: ref mean/c_meanfunc_zero.cpp:32-50
+            pm[i] = use_meta ? e.meta[src] : 0;
+        }
+        for (int d = 0; d <= D; d++) seg[d] = roff[d] = coff[d] = 0;
+        if (perm || !use_meta) {   // grouped copy: output segments + slab slots of k_wgrad (16-row / 64-column pieces per output)
+            if (use_meta) { for (int i = 0; i < e.n; i++) seg[pm[i] + 1]++; for (int d = 0; d < D; d++) seg[d + 1] += seg[d]; }
+            else seg[1] = e.n;
+            for (int d = 0; d < D; d++) {
+                const int a = seg[d], z = seg[d + 1];
+                roff[d + 1] = roff[d] + (z > a ? (z - 1) / 16 - a / 16 + 1 : 0);
+                coff[d + 1] = coff[d] + (z > a ? (z - 1) / 64 - a / 64 + 1 : 0);
+            }
+        }
+        off += up_payload_bytes(e.n, D);
+    };
+    for (size_t k = 0; k < ents.size(); k++) {
+        pack(ents[k], ents[k].slot, perms[k].data());
+        if (!ident[k]) pack(ents[k], ents[k].slot + S, nullptr);   // caller order (factor export / predict in that order)
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_stage, c->h_stage, off, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_stage, c->stream));
+    c->stage_pending = true;
+    hipLaunchKernelGGL(k_scatter_patients, dim3(nent), dim3(256), 0, c->stream, (const char *)c->d_stage, D, ldn, c->d_pn, c->d_pt,
+                       c->d_py, c->d_pmeta, c->d_pseg, c->d_proff, c->d_pcoff);
+    HIPCHK(c, hipGetLastError());
+    for (size_t k = 0; k < ents.size(); k++) {
+        const int s = ents[k].slot;
+        c->h_n[s] = ents[k].n;
+        c->h_perm[s] = std::move(perms[k]);
+        c->h_perm_identity[s] = ident[k];
+    }
+    c->last_nbatch = 0;   // cached batch selection / factors no longer describe the resident patients
+    c->last_has_inverse = false;
+    return MEDGP_OK;
+}
+}  // namespace
 
 int medgp_set_patient(medgp_ctx *c, int slot, int n, const int32_t *meta, const float *t, const float *y) {
     if (!c) return MEDGP_ERR_ARG;
     if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
-    if (slot < 0 || slot >= c->max_slots) return fail(c, MEDGP_ERR_CAPACITY, "slot %d outside [0, %d)", slot, c->max_slots);
-    if (n < 0 || n > c->max_n) return fail(c, MEDGP_ERR_CAPACITY, "n = %d outside [0, %d]", n, c->max_n);
-    if (n > 0 && (!t || !y)) return fail(c, MEDGP_ERR_ARG, "t / y is NULL");
-    const int D = c->D, ldn = c->ldn;
-    const bool use_meta = (c->kidx == MEDGP_KERNEL_LMC_SM);
-    if (use_meta && n > 0 && !meta) return fail(c, MEDGP_ERR_ARG, "meta is NULL for the multi-output kernel");
-    // stable grouping by output (counting sort)
-    std::vector<int> seg(D + 1, 0), perm(n);
-    if (use_meta) {
-        for (int i = 0; i < n; i++) {
-            if (meta[i] < 0 || meta[i] >= D) return fail(c, MEDGP_ERR_ARG, "meta[%d] = %d outside [0, %d)", i, meta[i], D);
-            seg[meta[i] + 1]++;
-        }
-        for (int d = 0; d < D; d++) seg[d + 1] += seg[d];
-        std::vector<int> pos(seg.begin(), seg.end() - 1);
-        for (int i = 0; i < n; i++) perm[pos[meta[i]]++] = i;
-    } else {
-        seg[1] = n;
-        for (int i = 0; i < n; i++) perm[i] = i;
+    return upload_patients(c, {UpEntry{slot, n, meta, t, y}});
+}
+
+int medgp_set_patients(medgp_ctx *c, int nslots, const int32_t *slots, const int64_t *offsets, const int32_t *meta,
+                       const float *t, const float *y) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
+    if (nslots < 1 || !slots || !offsets) return fail(c, MEDGP_ERR_ARG, "medgp_set_patients: bad argument");
+    std::vector<UpEntry> ents(nslots);
+    for (int k = 0; k < nslots; k++) {
+        const int64_t a = offsets[k], z = offsets[k + 1];
+        if (a < 0 || z < a || z - a > c->max_n) return fail(c, MEDGP_ERR_CAPACITY, "offsets[%d..%d] = %lld..%lld: bad length", k, k + 1, (long long)a, (long long)z);
+        ents[k] = UpEntry{slots[k], (int)(z - a), meta ? meta + a : nullptr, t ? t + a : nullptr, y ? y + a : nullptr};
     }
-    bool ident = true;
-    for (int i = 0; i < n; i++) ident = ident && (perm[i] == i);
-    std::vector<double> ht(ldn, 0.0), hy(ldn, 0.0);
-    std::vector<int> hm(ldn, 0);
-    for (int i = 0; i < n; i++) {
-        ht[i] = (double)t[perm[i]];
-        hy[i] = (double)y[perm[i]];   // zero mean: ref mean/c_meanfunc_zero.cpp:32-50
-        hm[i] = use_meta ? meta[perm[i]] : 0;
-    }
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(c->d_pt + (size_t)slot * ldn, ht.data(), sizeof(double) * ldn, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_py + (size_t)slot * ldn, hy.data(), sizeof(double) * ldn, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_pmeta + (size_t)slot * ldn, hm.data(), sizeof(int) * ldn, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_pseg + (size_t)slot * (D + 1), seg.data(), sizeof(int) * (D + 1), hipMemcpyHostToDevice, c->stream));
-    // slab slots of k_wgrad: 16-row pieces and 64-column pieces each output's segment intersects
-    std::vector<int> roff(D + 1, 0), coff(D + 1, 0);
-    for (int d = 0; d < D; d++) {
-        const int a = seg[d], e = seg[d + 1];
-        roff[d + 1] = roff[d] + (e > a ? (e - 1) / 16 - a / 16 + 1 : 0);
-        coff[d + 1] = coff[d] + (e > a ? (e - 1) / 64 - a / 64 + 1 : 0);
-    }
-    HIPCHK(c, hipMemcpyAsync(c->d_proff + (size_t)slot * (D + 1), roff.data(), sizeof(int) * (D + 1), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_pcoff + (size_t)slot * (D + 1), coff.data(), sizeof(int) * (D + 1), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_pn + slot, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->h_n[slot] = n;
-    c->h_perm[slot] = perm;
-    c->h_perm_identity[slot] = ident ? 1 : 0;
-    return MEDGP_OK;
+    return upload_patients(c, ents);
 }
 
 int medgp_set_prior(medgp_ctx *c, int slot, const uint8_t *flag, const int32_t *type, const uint8_t *is_exp,
@@ -568,19 +667,24 @@ int medgp_nlml_grad_device(medgp_ctx *c, int nbatch, const int32_t *slots, const
                            double *nlml_dev, double *grad_dev, int32_t *status_dev) {
     if (!c) return MEDGP_ERR_ARG;
     if (!slots || !theta_dev || !nlml_dev) return fail(c, MEDGP_ERR_ARG, "NULL argument");
-    if (flag_grad && !grad_dev) return fail(c, MEDGP_ERR_ARG, "grad is NULL with flag_grad set");
+    if (flag_grad & ~(MEDGP_FLAG_GRAD | MEDGP_FLAG_KEEP_FACTOR)) return fail(c, MEDGP_ERR_ARG, "unknown bits in flag_grad = %d", flag_grad);
+    const int grad = flag_grad & MEDGP_FLAG_GRAD;
+    const bool keep = (flag_grad & MEDGP_FLAG_KEEP_FACTOR) != 0;
+    if (grad && !grad_dev) return fail(c, MEDGP_ERR_ARG, "grad is NULL with flag_grad set");
     if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
     HIPCHK(c, hipSetDevice(c->device));
     int max_n = 0, rc;
-    if ((rc = set_batch(c, nbatch, slots, &max_n))) return rc;
-    return run_pipeline(c, nbatch, max_n, theta_dev, flag_grad, false, 3, nlml_dev, grad_dev, status_dev);
+    // factor wanted but no gradient: patients that were not uploaded grouped by output are evaluated in the CALLER's order,
+    // so that L^-1 is the factor the reference would hand to GP_Regression::predict (ref: core/gp_regression.cpp:181-196)
+    if ((rc = set_batch(c, nbatch, slots, &max_n, keep && !grad))) return rc;
+    return run_pipeline(c, nbatch, max_n, theta_dev, grad, keep, 3, nlml_dev, grad_dev, status_dev);
 }
 
 int medgp_nlml_grad(medgp_ctx *c, int nbatch, const int32_t *slots, const double *theta, int flag_grad, double *nlml,
                     double *grad, int32_t *status) {
     if (!c) return MEDGP_ERR_ARG;
     if (!slots || !theta || !nlml) return fail(c, MEDGP_ERR_ARG, "NULL argument");
-    if (flag_grad && !grad) return fail(c, MEDGP_ERR_ARG, "grad is NULL with flag_grad set");
+    if ((flag_grad & MEDGP_FLAG_GRAD) && !grad) return fail(c, MEDGP_ERR_ARG, "grad is NULL with flag_grad set");
     if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
     if (nbatch < 1 || nbatch > c->max_batch) return fail(c, MEDGP_ERR_CAPACITY, "nbatch %d outside [1, %d]", nbatch, c->max_batch);
     HIPCHK(c, hipSetDevice(c->device));
@@ -589,7 +693,7 @@ int medgp_nlml_grad(medgp_ctx *c, int nbatch, const int32_t *slots, const double
     int rc = medgp_nlml_grad_device(c, nbatch, slots, c->d_theta, flag_grad, c->d_nlml, c->d_grad, c->d_status_out);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(nlml, c->d_nlml, sizeof(double) * nbatch, hipMemcpyDeviceToHost, c->stream));
-    if (flag_grad) HIPCHK(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * nbatch * H, hipMemcpyDeviceToHost, c->stream));
+    if (flag_grad & MEDGP_FLAG_GRAD) HIPCHK(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * nbatch * H, hipMemcpyDeviceToHost, c->stream));
     if (status) HIPCHK(c, hipMemcpyAsync(status, c->d_status_out, sizeof(int32_t) * nbatch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MEDGP_OK;
@@ -598,17 +702,41 @@ int medgp_nlml_grad(medgp_ctx *c, int nbatch, const int32_t *slots, const double
 int medgp_get_factor(medgp_ctx *c, int b, float *alpha, float *linv, float *beta) {
     if (!c) return MEDGP_ERR_ARG;
     if (b < 0 || b >= c->last_nbatch) return fail(c, MEDGP_ERR_ARG, "batch entry %d outside the last call's [0, %d)", b, c->last_nbatch);
+    if (!c->last_has_inverse)
+        return fail(c, MEDGP_ERR_ARG, "no factor available: the last call formed neither gradients nor the factor "
+                                      "(pass MEDGP_FLAG_GRAD or MEDGP_FLAG_KEEP_FACTOR to medgp_nlml_grad)");
     HIPCHK(c, hipSetDevice(c->device));
-    const int slot = c->h_bslot[b], n = c->h_n[slot], ld = c->ldn;
+    const int S = c->max_slots, ld = c->ldn;
+    int eff = c->h_bslot[b];
+    const int slot = eff >= S ? eff - S : eff, n = c->h_n[slot];
     const std::vector<int> &perm = c->h_perm[slot];
     int st = 0;
     HIPCHK(c, hipMemcpyAsync(&st, c->d_status + b, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (st < 0) return fail(c, MEDGP_ERR_ARG, "batch entry %d failed (status %d); no factor available", b, st);
+    if (linv && eff < S && !c->h_perm_identity[slot]) {
+        // The entry was factored in the grouped order (the gradient needs it), but L^-1 is order dependent: re-factor this
+        // one entry from the caller-order copy of the patient (same hyper block; tables, Gram, factor and inverse redone).
+        const int shadow = slot + S;
+        HIPCHK(c, hipMemcpyAsync(c->d_one_slot, &shadow, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        MedgpDev V = shifted_view(c->dev, b);
+        V.bslot = c->d_one_slot;
+        const bool prof = c->profiling;
+        c->profiling = false;   // not part of the evaluation being measured
+        int rc = run_pipeline_one(c, c->stream, V, 1, n, nullptr, 0, true, 1, nullptr, nullptr, nullptr);
+        c->profiling = prof;
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->d_bslot + b, c->d_one_slot, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&st, c->d_status + b, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->h_bslot[b] = eff = shadow;
+        if (st < 0) return fail(c, MEDGP_ERR_ARG, "batch entry %d: the factorisation in the caller's order failed (status %d)", b, st);
+    }
+    const bool caller_order = eff >= S || c->h_perm_identity[slot];
     if (alpha) {
         std::vector<double> ha(n);
         HIPCHK(c, hipMemcpy(ha.data(), c->dev.alpha + (size_t)b * ld, sizeof(double) * n, hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; i++) alpha[perm[i]] = (float)ha[i];
+        for (int i = 0; i < n; i++) alpha[caller_order ? i : perm[i]] = (float)ha[i];
     }
     if (beta) {
         double sc[4];
@@ -616,8 +744,6 @@ int medgp_get_factor(medgp_ctx *c, int b, float *alpha, float *linv, float *beta
         *beta = (float)sc[1];
     }
     if (linv) {
-        if (!c->h_perm_identity[slot])
-            return fail(c, MEDGP_ERR_ARG, "L^-1 is only exported for patients already grouped by output (the reference loader's order)");
         std::vector<double> hx((size_t)n * ld);
         HIPCHK(c, hipMemcpy(hx.data(), c->dev.Linv + (size_t)b * ld * ld, sizeof(double) * n * ld, hipMemcpyDeviceToHost));
         for (int i = 0; i < n; i++)
@@ -642,10 +768,12 @@ static int fit_predict_impl(medgp_ctx *c, int nbatch, const int32_t *slots, cons
         if ((rc = dalloc(c, &c->d_meta2, cap))) return rc;
         if ((rc = dalloc(c, &c->d_mean, cap))) return rc;
         if ((rc = dalloc(c, &c->d_var, cap))) return rc;
-        if ((rc = dalloc(c, &c->d_ks, (size_t)cap * c->ldn))) return rc;
+        if ((rc = dalloc(c, &c->d_ks, (size_t)cap * c->ldn))) return rc;   // k* -> v = L^-1 k* work rows
         c->pred_cap = cap;
     }
     int max_n = 0, rc;
+    // patients are used in the caller's order when that differs from the grouped one?  No: mean / var are permutation
+    // invariant, the grouped copy serves.
     if ((rc = set_batch(c, nbatch, slots, &max_n))) return rc;
     std::vector<double> ht2(ntot);
     std::vector<int> hm2(ntot, 0);
@@ -659,10 +787,11 @@ static int fit_predict_impl(medgp_ctx *c, int nbatch, const int32_t *slots, cons
     HIPCHK(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * c->H * nbatch, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_t2, ht2.data(), sizeof(double) * ntot, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_meta2, hm2.data(), sizeof(int) * ntot, hipMemcpyHostToDevice, c->stream));
-    if ((rc = run_pipeline(c, nbatch, max_n, c->d_theta, 0, true, 1, nullptr, nullptr, nullptr))) return rc;
+    // factor + z = L^-1 y only (no inverse): k* rides along as one more right-hand side in k_predict
+    if ((rc = run_pipeline(c, nbatch, max_n, c->d_theta, 0, false, 1, nullptr, nullptr, nullptr, true))) return rc;
     {
         Launcher l(c, KID_PREDICT);
-        hipLaunchKernelGGL(k_predict_v0, dim3(nstar, nbatch), dim3(256), 0, c->stream, c->dev, nstar, c->d_meta2, c->d_t2, c->d_ks, c->d_mean, c->d_var);
+        hipLaunchKernelGGL(k_predict, dim3(nstar, nbatch), dim3(256), 0, c->stream, c->dev, nstar, c->d_meta2, c->d_t2, c->d_ks, c->d_mean, c->d_var);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(mean, c->d_mean, sizeof(float) * ntot, hipMemcpyDeviceToHost, c->stream));

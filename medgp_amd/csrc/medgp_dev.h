@@ -28,6 +28,8 @@ struct MedgpDev {
     int ldn, max_slots, max_batch;
     int hyp_stride;          // doubles per batch entry in `hyp`
     double pi;
+    int dbg_fail;            // test hook (MEDGP_DEBUG_FAIL_ATTEMPTS=k): the first k factorisation attempts of every problem are
+                             // treated as failed, which drives the reference's jitter loop deterministically (0 in production)
     // patients
     const int *pn;           // [slot] n
     const double *pt, *py;   // [slot][ldn]

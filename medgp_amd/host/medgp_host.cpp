@@ -208,7 +208,10 @@ bool c_inference_hip::compute_nlml(const bool &flag_grad, const vector<int> &met
     int32_t slot = 0, st = -1;
     vector<double> g(flag_grad ? H : 0);
     double f = 0.0;
-    if (medgp_nlml_grad(ctx_, 1, &slot, theta.data(), flag_grad ? 1 : 0, &f, flag_grad ? g.data() : nullptr, &st)) {
+    // the factor outputs (chol_alpha / chol_factor_inv / beta) are formed only when the caller passes buffers for them
+    const bool want_factor = chol_alpha || chol_factor_inv;
+    const int flags = (flag_grad ? MEDGP_FLAG_GRAD : 0) | (want_factor ? MEDGP_FLAG_KEEP_FACTOR : 0);
+    if (medgp_nlml_grad(ctx_, 1, &slot, theta.data(), flags, &f, flag_grad ? g.data() : nullptr, &st)) {
         err = medgp_last_error(ctx_); std::cout << "ERROR: " << err << std::endl; return false;
     }
     status = st;
@@ -216,21 +219,9 @@ bool c_inference_hip::compute_nlml(const bool &flag_grad, const vector<int> &met
     if (st > 0) std::cout << "WARNING: Cholesky decomposition failed! jitter rounds = " << st << std::endl;
     nlml = f;
     if (flag_grad) dnlml = g;   // ref: dnlml cleared + filled in theta order (c_inference_exact.cpp:158-160)
-    if (chol_alpha || chol_factor_inv) {
+    if (want_factor) {
         float b = 0.f;
-        // the factor exists only when the inverse was formed (flag_grad) -- re-run the inverse path otherwise
-        if (!flag_grad) {
-            vector<float> m(1), v(1);
-            int32_t s2;
-            vector<int32_t> m2(1, meta.empty() ? 0 : meta[0]);
-            vector<float> t2(1, x[0]);
-            if (medgp_fit_predict(ctx_, 0, theta.data(), 1, m2.data(), t2.data(), m.data(), v.data(), &s2)) return false;
-        }
-        int rc = medgp_get_factor(ctx_, 0, chol_alpha, chol_factor_inv, &b);
-        if (rc) {   // not grouped by output: alpha is still exported, L^-1 is not
-            rc = medgp_get_factor(ctx_, 0, chol_alpha, nullptr, &b);
-            if (rc) { err = medgp_last_error(ctx_); return false; }
-        }
+        if (medgp_get_factor(ctx_, 0, chol_alpha, chol_factor_inv, &b)) { err = medgp_last_error(ctx_); std::cout << "ERROR: " << err << std::endl; return false; }
         beta = b;
     }
     return true;

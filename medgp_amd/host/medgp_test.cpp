@@ -136,14 +136,16 @@ bool run_test_one(c_experiment &curr_exp, medgp_ctx *ctx, const string &PAN, int
             vector<int32_t> slots, meta2, which;
             vector<float> t2;
             vector<double> thetas;
+            // the training subsets of the whole batch are packed into ONE upload (medgp_set_patients): one H2D transfer and
+            // no device wait per problem (one medgp_set_patient per problem was 8 copies + a stream sync each)
+            vector<int32_t> pm; vector<float> pt, py;
+            vector<int64_t> poff(1, 0);
             for (int k = c0; k < std::min(np, c0 + max_batch); k++) {
                 const Problem &p = problems[k];
                 if (p.train.empty()) continue;
-                vector<int> m; vector<float> t, y;
-                for (int ii : p.train) { m.push_back(meta_array[ii]); t.push_back(time_array[ii]); y.push_back(value_array[ii]); }
-                const int slot = (int)slots.size();
-                if (medgp_set_patient(ctx, slot, (int)t.size(), kidx == 7 ? (const int32_t *)m.data() : nullptr, t.data(), y.data())) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
-                slots.push_back(slot);
+                for (int ii : p.train) { pm.push_back(meta_array[ii]); pt.push_back(time_array[ii]); py.push_back(value_array[ii]); }
+                poff.push_back((int64_t)pt.size());
+                slots.push_back((int)slots.size());
                 which.push_back(k);
                 meta2.push_back(meta_array[p.test_idx]);
                 t2.push_back(time_array[p.test_idx]);
@@ -151,6 +153,7 @@ bool run_test_one(c_experiment &curr_exp, medgp_ctx *ctx, const string &PAN, int
                 thetas.insert(thetas.end(), th.begin(), th.end());
             }
             if (slots.empty()) continue;
+            if (medgp_set_patients(ctx, (int)slots.size(), slots.data(), poff.data(), kidx == 7 ? pm.data() : nullptr, pt.data(), py.data())) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
             vector<float> mean(slots.size()), var(slots.size());
             vector<int32_t> st(slots.size());
             if (medgp_fit_predict_batch(ctx, (int)slots.size(), slots.data(), thetas.data(), meta2.data(), t2.data(), mean.data(), var.data(), st.data())) {

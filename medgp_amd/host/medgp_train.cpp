@@ -119,7 +119,13 @@ int main(int argc, const char *argv[]) {
     const int nslot = std::max<int>(1, (int)live.size());
     if (!live.empty()) {
         if (medgp_create(&ctx, device, kidx, kparam[0], kparam[1], kparam[2])) { cout << "ERROR: " << medgp_last_error(nullptr) << endl; return 1; }
-        max_batch = std::max(1, max_batch);
+        {   // evaluations that can exist at once, and what fits a memory budget: every batch entry owns two ldn x ldn fp64
+            // matrices (medgp_reserve allocates them up front); the screening and lock-step loops chunk by max_batch
+            const long long ldn = (max_n + 63) / 64 * 64;
+            const long long want = (long long)live.size() * std::max(curr_exp.get_scg_init_num(), 1);
+            const long long fit = std::max<long long>(1, (48LL << 30) / (16 * ldn * ldn + 4096));
+            max_batch = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(std::max(1, max_batch), want), fit));
+        }
         if (medgp_reserve(ctx, nslot, max_n, max_batch)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
         for (size_t s = 0; s < live.size(); s++) {
             Patient &p = *live[s];

@@ -45,19 +45,14 @@ def main(argv=None):
     ap.add_argument("--gather", action="store_true")
     ap.add_argument("--backend", default=None, help="nccl (default with GPUs) or gloo")
     ap.add_argument("--max-batch", type=int, default=1024)
+    ap.add_argument("--timeout-hours", type=float, default=48.0,
+                    help="process-group timeout: how long a finished rank waits for the slowest shard")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        backend = args.backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend)
 
     cfg = json.load(open(args.cfg))
     pans = [p for p in open(args.pan_list).read().split() if p]
@@ -75,7 +70,17 @@ def main(argv=None):
         with open(os.path.join(cfg["exp_train_dir"], f"train_rank{rank}.log"), "w") as f:
             f.write(r.stdout)
     if world > 1:
+        # The process group is created only now, AFTER the training subprocess has returned: lock-step SCG runs until the
+        # slowest patient of a shard finishes, so ranks can arrive hours apart, and a group created up front would have its
+        # first collective (below) aborted by the default watchdog timeout (nccl 10 min).  The generous timeout covers the
+        # rendezvous skew itself.
+        import datetime
         import torch
+        import torch.distributed as dist
+        backend = args.backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend, timeout=datetime.timedelta(hours=args.timeout_hours))
         dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
         flag = torch.tensor([rc], dtype=torch.int64, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)

@@ -51,7 +51,7 @@ def appendix_a():
             p = os.path.join(td, "a.bin")
             subprocess.check_call([exe, str(D), str(N), str(Q), str(R), "0", p])
             D_, N_, Q_, R_, meta, x, y, th = load_bin(p)
-            want_grad = N <= 512
+            want_grad = True   # N = 2048 too: 1114 gradient components of the multi-CU path at its real size
             r = O.nlml_grad(7, Q, D, R, meta, x, y, th, flag_grad=want_grad, nthreads=8)
             out = dict(D=D, N=N, Q=Q, R=R, meta=meta, t=x, y=y, theta=th, ref_fp32_nlml=ref,
                        oracle_nlml=r["nlml"], oracle_status=r["status"])
@@ -89,6 +89,51 @@ def fastkernel():
         print(f"fastkernel Q={Q} D={D} R={R}: B {B.shape}, resp {resp.shape}")
 
 
+def config5():
+    """BASELINE config 5 at full size: D=64, N=4096, Q=5, R=8 (H=2954), a random 50 % of the A entries exactly zero
+    and clamped (test-time prior, ref: prior/c_prior.cpp:118-140), hierarchical-gamma prior (mode 2, eta = beta_lam =
+    0.01; ref: scripts/gen_medgpc_example.sh:11).  Expected values: the oracle (blocked gradient form), fp64."""
+    from medgp_amd import synth
+    D, N, Q, R, seed = 64, 4096, 5, 8, 5005
+    meta, t, y = synth.patient(seed, 0, D, N)
+    th = synth.theta(seed, 0, 7, Q, D, R, sparse_frac=0.5)
+    pr = O.Prior.hier_gamma(Q, D, R, 0.01, 0.01)
+    z = np.where(th[D:D + Q * D * R] == 0.0)[0] + D
+    pr.type[z] = 0
+    r = O.nlml_grad(7, Q, D, R, meta, t, y, th, flag_grad=True, prior=pr, nthreads=8)
+    assert r["ok"] and r["status"] == 0
+    np.savez_compressed(os.path.join(HERE, f"config5_D{D}_N{N}.npz"), D=D, N=N, Q=Q, R=R, seed=seed, meta=meta, t=t, y=y,
+                        theta=th, clamped=z, oracle_nlml=r["nlml"], oracle_grad=r["grad"], oracle_status=r["status"])
+    print(f"config5 D={D} N={N}: oracle nlml {r['nlml']:.10f}, {z.size} clamped A entries")
+
+
+def fastkernel_gram():
+    """Full Gram matrices assembled ONLY from the reference's Python factors: K[i][j] = sum_q B_q[m_i][m_j] k_q(|t_i - t_j|)
+    with B_q from fastkernel.compute_B_matrix (fastkernel.py:13-22) and k_q from fastkernel.compute_sm_1d (:33-48) evaluated
+    at the pairwise distances (np.pi, as that file uses).  Pins rows a3-a8 (hyper split, B_q, distances, LMC-SM Gram) end to end
+    to reference-produced numbers; the noise diagonal sigma_d^2 = exp(2 theta_d) (ref: c_likelihood.cpp:38-43) is added by the test."""
+    import importlib.util
+    from medgp_amd import synth
+    spec = importlib.util.spec_from_file_location("ref_fastkernel", "/root/reference/medgpc/visualization/fastkernel.py")
+    fk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fk)
+    for (Q, D, R, N, seed) in [(5, 2, 2, 60, 11), (5, 24, 8, 96, 12), (3, 7, 4, 70, 13)]:
+        meta, t, y = synth.patient(seed, 0, D, N, interleave=(D == 7))
+        th = synth.theta(seed, 0, 7, Q, D, R)
+        B = np.stack(fk.compute_B_matrix(Q, D, R, th))
+        mu = np.exp(th[D + Q * D * R: D + Q * D * R + Q])
+        v = np.exp(th[D + Q * D * R + Q: D + Q * D * R + 2 * Q])
+        dist = np.abs(t.astype(np.float64)[:, None] - t.astype(np.float64)[None, :]).reshape(-1, 1)
+        K = np.zeros((N, N))
+        for q in range(Q):
+            kq = fk.compute_sm_1d(mu[q], v[q] ** 2, dist)[:, 0].reshape(N, N)
+            K += B[q][meta[:, None], meta[None, :]] * kq
+        np.savez_compressed(os.path.join(HERE, f"fastkernel_gram_Q{Q}_D{D}_R{R}.npz"), Q=Q, D=D, R=R, N=N, meta=meta, t=t, y=y,
+                            theta=th, K=K)
+        print(f"fastkernel gram Q={Q} D={D} R={R} N={N}: cond {np.linalg.cond(K + np.diag(np.exp(2 * th[meta]))):.2e}")
+
+
 if __name__ == "__main__":
-    appendix_a()
-    fastkernel()
+    which = sys.argv[1:] or ["appendix_a", "fastkernel", "fastkernel_gram", "config5"]
+    for w in which:
+        globals()[w]()

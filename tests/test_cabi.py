@@ -51,3 +51,15 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".h", ".hip", ".cpp", ".hpp", "Makefile")):
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "medgp_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(dp, fn)
+
+
+def test_integration_snippet_compiles_against_reference_headers():
+    """INTEGRATION.md section 2's c_inference_hip class, extracted and syntax-checked against the reference's own
+    headers (build container only: /root/reference does not exist on the GPU box)."""
+    import subprocess
+    if not os.path.isdir("/root/reference/medgpc/src"):
+        pytest.skip("reference tree not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.path.join(root, "scratch", "check_integration_snippet.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "syntax OK" in r.stdout

@@ -57,7 +57,7 @@ def test_oracle_prior_mode2_vs_recorded_reference():
     assert abs(r["nlml"] - ref) <= 1e-6 * ref
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "fastkernel_*.npz"))))
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "fastkernel_Q*.npz"))))
 def test_oracle_vs_fastkernel(path):
     """B_q and k_q against the reference's own Python (fastkernel.py:13-48), which uses numpy's pi."""
     g = np.load(path)
@@ -70,6 +70,23 @@ def test_oracle_vs_fastkernel(path):
     # with the reference C++'s truncated literal the kernel moves by O(1e-8) only
     k_ref = np.array([O.sm_k(x * x, g["mu"][0], g["v"][0]) for x in g["x"]])
     assert np.abs(k_ref - g["resp"][0]).max() < 1e-6
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "fastkernel_gram_*.npz"))))
+def test_oracle_gram_vs_fastkernel_gram(path):
+    """Rows a3-a8 end to end: the oracle's full Gram matrix (theta split, B_q, distances, LMC-SM sum) against Gram matrices
+    assembled only from the reference's own Python factors (tests/golden/make_golden.py::fastkernel_gram)."""
+    g = np.load(path)
+    Q, D, R = int(g["Q"]), int(g["D"]), int(g["R"])
+    K = O.gram(7, Q, D, R, g["meta"], g["t"], g["theta"], pi=np.pi)
+    noise = np.exp(2 * g["theta"][g["meta"]])    # ref: likelihoods/c_likelihood.cpp:38-43, c_inference_exact.cpp:88-92
+    np.testing.assert_allclose(K - np.diag(noise), g["K"], rtol=0, atol=5e-13 * np.abs(g["K"]).max())   # O.gram adds the noise
+    r = O.nlml_grad(7, Q, D, R, g["meta"], g["t"], g["y"], g["theta"], flag_grad=False, pi=np.pi)
+    Kfull = g["K"] + np.diag(noise)
+    L = sla.cholesky(Kfull, lower=True)
+    y = g["y"].astype(np.float64)
+    ref = 0.5 * y @ sla.cho_solve((L, True), y) + np.log(np.diag(L)).sum() + 0.5 * y.size * np.log(2 * np.pi)
+    assert abs(r["nlml"] - ref) <= 1e-11 * abs(ref)
 
 
 @pytest.mark.parametrize("D,N,Q,R", [(2, 40, 3, 2), (5, 63, 2, 3)])

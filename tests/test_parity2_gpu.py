@@ -1,0 +1,276 @@
+"""GPU parity tests, part 2: BASELINE configs at full size against committed fixtures, the exact bench workload,
+the jitter / failure semantics against the oracle, the factor boundary (train(false) + predict in the caller's order),
+reference-derived Gram matrices, the packed upload.
+
+Tolerances as tests/test_parity_gpu.py (nlml 1e-10 relative, gradient 1e-6 of max(|g_h|, 1e-3 max|g|))."""
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+pytestmark = pytest.mark.gpu
+
+import medgp_amd
+from medgp_amd import synth
+from oracle import oracle as O
+from test_parity_gpu import assert_parity, make_ctx, GOLD
+
+
+def test_config5_full_size_vs_fixture():
+    """BASELINE config 5 at FULL size: D=64, N=4096, Q=5, R=8 (H=2954), half of the A entries exactly zero and clamped,
+    hierarchical-gamma prior (mode 2).  Expected values: committed oracle outputs (tests/golden/make_golden.py::config5)."""
+    g = np.load(os.path.join(GOLD, "config5_D64_N4096.npz"))
+    D, N, Q, R = int(g["D"]), int(g["N"]), int(g["Q"]), int(g["R"])
+    assert (D, N) == (64, 4096)
+    ctx = make_ctx(7, Q, D, R, [(g["meta"], g["t"], g["y"])])
+    f, ty, ex, p0, p1 = synth.hier_gamma_prior(Q, D, R, 0.01)
+    ty = ty.copy()
+    ty[g["clamped"]] = 0            # test-time clamp of the exactly-zero A entries (ref: c_prior.cpp:118-140)
+    ctx.set_prior(0, f, ty, ex, p0, p1)
+    nlml, grad, st = ctx.nlml_grad([0], g["theta"][None, :], True)
+    assert st[0] == int(g["oracle_status"]) == 0
+    assert_parity(nlml[0], grad[0], {"nlml": float(g["oracle_nlml"]), "grad": g["oracle_grad"]}, "config5")
+    assert np.all(grad[0][g["clamped"]] == 0.0)
+    n0, _, _ = ctx.nlml_grad([0], g["theta"][None, :], False)
+    assert abs(n0[0] - nlml[0]) <= 1e-12 * abs(nlml[0])
+    ctx.close()
+
+
+def test_headline_workload_deterministic():
+    """The bench workload itself: 512 patients x N=512, D=24, Q=5, R=8, hier-gamma prior, ONE call of 512 evaluations
+    (more entries than CUs: the one-workgroup-per-patient factorisation k_cholinv<4,4>, several passes per step).
+    Eight patients spread over the batch (first / last / both halves of the XCD groups) against the oracle."""
+    D, N, Q, R, P, seed = 24, 512, 5, 8, 512, 2024      # bench.py's defaults
+    pts, th = synth.cohort(seed, P, D, N, Q=Q, R=R)
+    ctx = medgp_amd.Context(7, Q, D, R)
+    ctx.reserve(P, N, P)
+    ctx.set_patients(np.arange(P), pts)
+    ctx.set_prior(-1, *synth.hier_gamma_prior(Q, D, R, 0.01))
+    nlml, grad, st = ctx.nlml_grad(np.arange(P), th, True)
+    assert np.all(st == 0) and np.all(np.isfinite(nlml)) and np.all(np.isfinite(grad))
+    pr = O.Prior.hier_gamma(Q, D, R, 0.01, 0.01)
+    for p in (0, 1, 63, 64, 255, 256, 389, 511):
+        ref = O.nlml_grad(7, Q, D, R, *pts[p], th[p], prior=pr, nthreads=8)
+        assert ref["status"] == 0
+        assert_parity(nlml[p], grad[p], ref, f"p{p}")
+    ctx.close()
+
+
+# ---- jitter / failure semantics (ref: c_inference_exact.cpp:96-111) ---------------------------------------------------
+def _dup_patient(n_unique, copies, D=1, seed=3):
+    rng = np.random.default_rng(seed)
+    tu = np.sort(rng.uniform(0, 60, n_unique)).astype(np.float32)
+    t = np.repeat(tu, copies)
+    m = np.zeros(t.size, np.int32) if D == 1 else np.tile(np.arange(D, dtype=np.int32), t.size // D + 1)[:t.size]
+    y = np.sin(0.3 * t).astype(np.float32)
+    return m, t, y
+
+
+def _theta_noise(th, D, jit_rounds):
+    """theta whose noise variance is (1 + jit_rounds) x the original: what the reference's retry loop evaluates
+    after `jit_rounds` additions of the noise vector (c_inference_exact.cpp:101-104)."""
+    th2 = th.copy()
+    th2[:D] += 0.5 * np.log1p(jit_rounds)
+    return th2
+
+
+@pytest.mark.parametrize("multi_cu", ["-1", "1"])
+def test_jitter_regimes_vs_oracle(multi_cu, monkeypatch):
+    """Exact duplicates of well separated time stamps: K is singular up to the noise and otherwise well conditioned.
+    Sweeping the noise through fp64 epsilon walks through the regimes of the reference's retry loop.  K is PSD in exact
+    arithmetic, so in the rounding-dominated regime WHICH attempt first succeeds is decided by rounding errors and cannot be
+    pinned across two correct implementations (the deterministic check of the retry machinery is the next test); pinned here:
+      * noise well above rounding: status 0 on both sides, value parity;
+      * noise absorbed by the diagonal (s + noise == s in fp64) or exactly zero: every retry adds the same nothing,
+        status -1 on both sides;
+      * in between: -1 <= status <= 10, finite outputs iff status >= 0;
+      * a healthy neighbour in the same batch is bit-identical whatever happens to the entry beside it.
+    multi_cu = 1 runs the host-driven retry loop of the multi-CU factorisation (n >= 128), -1 the in-kernel loop."""
+    monkeypatch.setenv("MEDGP_MULTI_CU", multi_cu)
+    D, Q, R = 1, 2, 1
+    tu = (30.0 * np.arange(48)).astype(np.float32)           # 30 h apart, length scales 5-6 h: unique points ~independent
+    t = np.repeat(tu, 3)                                     # n = 144: three 64-blocks
+    m = np.zeros(t.size, np.int32)
+    y = np.sin(0.3 * t).astype(np.float32)
+    good = synth.patient(9, 0, D, 144)
+    th = np.array([0.0, 0.7, -0.4, np.log(1 / 12.0), np.log(1 / 15.0), np.log(1 / (2 * synth.REF_PI * 6.0)),
+                   np.log(1 / (2 * synth.REF_PI * 5.0)), np.log(0.3), np.log(0.2)])
+    thg = synth.theta(2, 0, 7, Q, D, R)
+    ctx = make_ctx(7, Q, D, R, [(m, t, y), good], max_batch=8)
+    s_scale = O.gram(7, Q, D, R, m, t, th)[0, 0] - np.exp(2 * th[0])
+    seen = []
+    for rel in (1e-4, 1e-6, 1e-8, 1e-13, 3e-15, 1e-15, 4e-16, 2.3e-16, 1e-17, 0.0):
+        th2 = th.copy()
+        th2[0] = 0.5 * np.log(rel * s_scale) if rel > 0 else -800.0
+        nlml, grad, st = ctx.nlml_grad([1, 0, 1], np.stack([thg, th2, thg]), True)
+        ref = O.nlml_grad(7, Q, D, R, m, t, y, th2)
+        s = int(st[1])
+        seen.append(s)
+        assert st[0] == 0 and st[2] == 0
+        assert nlml[0] == nlml[2] and np.array_equal(grad[0], grad[2])
+        assert -1 <= s <= 10
+        assert np.isfinite(nlml[1]) == (s >= 0) and np.all(np.isfinite(grad[1])) == (s >= 0)
+        if rel >= 1e-8:
+            assert s == ref["status"] == 0
+            # cos(w dt) by the angle-difference identity: |dK| <= eps |w t| ~ 1e-13 s, i.e. 1e-13 / rel relative to the noise
+            assert abs(nlml[1] - ref["nlml"]) <= max(1e-10, 1e-12 / rel) * abs(ref["nlml"]), (rel, nlml[1], ref["nlml"])
+        if rel < 1.1e-16:
+            assert s == ref["status"] == -1
+    assert 0 in seen and -1 in seen
+    ctx.close()
+
+
+@pytest.mark.parametrize("multi_cu,fails", [("-1", 1), ("1", 1), ("-1", 3), ("1", 2), ("-1", 11), ("1", 11)])
+def test_jitter_retry_deterministic(multi_cu, fails, monkeypatch):
+    """The retry machinery driven BY CONSTRUCTION, not by rounding: MEDGP_DEBUG_FAIL_ATTEMPTS=k makes the library treat the
+    first k factorisation attempts of every problem as failed (a test hook; 0 in production).  The reference's loop
+    (c_inference_exact.cpp:99-111) then re-adds the noise vector k times: status == k, nlml == the nlml of K + (1 + k) noise
+    (the oracle at sigma' = sigma sqrt(1 + k)) to full parity, gradients likewise, except that the noise gradients use the
+    ORIGINAL sigma (c_inference_exact.cpp:194-202) and are therefore the oracle's divided by (1 + k); k = 11 exhausts the
+    10 retries: status -1 = the reference's `return false`.  Batch of ragged patients incl. one below the n > 2 guard."""
+    monkeypatch.setenv("MEDGP_MULTI_CU", multi_cu)
+    monkeypatch.setenv("MEDGP_DEBUG_FAIL_ATTEMPTS", str(fails))
+    D, Q, R = 3, 2, 2
+    ns = [150, 2, 200, 131]
+    pts = [synth.patient(12, p, D, n, interleave=(p == 3)) for p, n in enumerate(ns)]
+    th = np.stack([synth.theta(12, p, 7, Q, D, R) for p in range(len(ns))])
+    ctx = make_ctx(7, Q, D, R, pts)
+    nlml, grad, st = ctx.nlml_grad(np.arange(len(ns)), th, True)
+    nlml0, _, st0 = ctx.nlml_grad(np.arange(len(ns)), th, False)
+    assert st[1] == -1 and np.isnan(nlml[1])
+    for p in (0, 2, 3):
+        if fails > 10:
+            assert st[p] == -1 and st0[p] == -1 and np.isnan(nlml[p]) and np.all(np.isnan(grad[p]))
+            continue
+        assert st[p] == fails and st0[p] == fails
+        ref = O.nlml_grad(7, Q, D, R, *pts[p], _theta_noise(th[p], D, fails))
+        ref["grad"][:D] /= (1 + fails)
+        assert_parity(nlml[p], grad[p], ref, f"p{p} fails{fails}")
+        assert abs(nlml0[p] - nlml[p]) <= 1e-12 * abs(nlml[p])
+    ctx.close()
+
+
+def test_jitter_exhaustion_mixed_batch_multi_cu(monkeypatch):
+    """Host-driven retry of the multi-CU path with all three outcomes in one batch at n >= 128: healthy (0), exhausted (-1,
+    noise exactly zero on duplicates), n <= 2 (-1 from the guard), plus whatever the borderline entry does."""
+    monkeypatch.setenv("MEDGP_MULTI_CU", "1")
+    D, Q, R = 2, 2, 2
+    m, t, y = _dup_patient(40, 4, D=2)     # n = 160, duplicates within each output
+    good = synth.patient(10, 0, D, 200)
+    tiny = (np.array([0, 1], np.int32), np.array([1, 2], np.float32), np.array([0, 1], np.float32))
+    th = synth.theta(4, 0, 7, Q, D, R)
+    th_sing = th.copy(); th_sing[:D] = -800.0
+    th_edge = th.copy(); th_edge[:D] = 0.5 * np.log(3e-16)
+    ctx = make_ctx(7, Q, D, R, [(m, t, y), good, tiny], max_batch=8)
+    nlml, grad, st = ctx.nlml_grad([1, 0, 2, 0, 1], np.stack([th, th_sing, th, th_edge, th]), True)
+    ref = O.nlml_grad(7, Q, D, R, *good, th)
+    assert st[0] == st[4] == 0 and st[1] == -1 and st[2] == -1
+    assert_parity(nlml[0], grad[0], ref, "healthy")
+    assert nlml[4] == nlml[0] and np.array_equal(grad[4], grad[0])
+    assert np.isnan(nlml[1]) and np.isnan(nlml[2])
+    assert O.nlml_grad(7, Q, D, R, m, t, y, th_sing)["status"] == -1
+    assert np.isfinite(nlml[3]) == (st[3] >= 0)
+    ctx.close()
+
+
+# ---- the factor boundary ---------------------------------------------------------------------------------------------
+def _reference_predict(kidx, Q, D, R, m, t, alpha, linv, theta, m2, t2):
+    """GP_Regression::predict restated with numpy on the reference's buffers (ref: core/gp_regression.cpp:164-196):
+    mean = K*^T chol_alpha (sgemv), V = chol_factor_inv K* (strmm with the LOWER triangle), var = k** - |V col|^2 + lik."""
+    n = t.size
+    mm = np.concatenate([m, m2]).astype(np.int32)
+    tt = np.concatenate([t, t2]).astype(np.float32)
+    Kall = O.gram(kidx, Q, D, R, mm, tt, theta)         # includes the noise on its diagonal
+    noise = np.exp(2 * theta[mm]) if kidx == 7 else np.full(mm.size, np.exp(2 * theta[0]))
+    Ks = Kall[:n, n:]
+    kss = np.diag(Kall)[n:] - noise[n:]
+    mean = Ks.T @ alpha.astype(np.float64)
+    V = np.tril(linv.astype(np.float64)) @ Ks
+    return mean, kss - (V * V).sum(0) + noise[n:]
+
+
+def test_train_false_then_reference_predict():
+    """main_one_test.cpp:354-399 through the INTEGRATION.md-shaped adapter: the training set is `past + appended current
+    observations` (NOT grouped by output), GP_Regression::train(false) -> compute_nlml(flag_grad = false) must leave
+    chol_alpha / chol_factor_inv valid and in the caller's order for the reference's unchanged predict."""
+    D, Q, R = 3, 3, 2
+    m, t, y = synth.patient(21, 0, D, 150, interleave=True)       # caller order: not grouped
+    th = synth.theta(21, 0, 7, Q, D, R)
+    ctx = make_ctx(7, Q, D, R, [(m, t, y)])
+    # flag_grad = 0 alone forms no factor: get_factor must refuse instead of returning stale data
+    ctx.nlml_grad([0], th[None, :], False)
+    with pytest.raises(medgp_amd.MedgpError):
+        ctx.get_factor(0, t.size)
+    nl, _, st = ctx.nlml_grad([0], th[None, :], False, keep_factor=True)        # train(false)
+    assert st[0] == 0
+    ref = O.nlml_grad(7, Q, D, R, m, t, y, th, want_alpha=True, want_linv=True)   # the oracle works in the caller's order
+    assert abs(nl[0] - ref["nlml"]) <= 1e-10 * abs(ref["nlml"])
+    alpha, linv, beta = ctx.get_factor(0, t.size)
+    np.testing.assert_allclose(alpha, ref["alpha"], rtol=2e-6, atol=1e-6 * np.abs(ref["alpha"]).max())
+    np.testing.assert_allclose(linv, ref["linv"], rtol=2e-6, atol=1e-6 * np.abs(ref["linv"]).max())
+    assert np.all(np.triu(linv, 1) == 0) and abs(beta - ref["beta"]) <= 1e-6 * abs(ref["beta"])
+    m2 = np.array([1, 0, 2], np.int32)
+    t2 = np.array([float(t[7]), 33.25, 180.0], np.float32)
+    mean, var = _reference_predict(7, Q, D, R, m, t, alpha, linv, th, m2, t2)
+    rp = O.fit_predict(7, Q, D, R, m, t, y, th, m2, t2)
+    np.testing.assert_allclose(mean, rp["mean"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(var, rp["var"], rtol=1e-4, atol=1e-5)
+    gm, gv, gs = ctx.fit_predict(0, th, m2, t2)          # the throughput route (no inverse formed)
+    assert gs == 0
+    np.testing.assert_allclose(gm, rp["mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gv, rp["var"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(medgp_amd.MedgpError):
+        ctx.get_factor(0, t.size)                        # fit_predict keeps no factor
+    # gradient call on the same (ungrouped) patient: evaluated grouped, L^-1 still comes back in the caller's order
+    nl2, g2, _ = ctx.nlml_grad([0], th[None, :], True)
+    assert_parity(nl2[0], g2[0], ref)
+    a2, l2, b2 = ctx.get_factor(0, t.size)
+    np.testing.assert_allclose(a2, ref["alpha"], rtol=2e-6, atol=1e-6 * np.abs(ref["alpha"]).max())
+    np.testing.assert_allclose(l2, ref["linv"], rtol=2e-6, atol=1e-6 * np.abs(ref["linv"]).max())
+    a3, l3, _ = ctx.get_factor(0, t.size)                # asking twice is stable
+    assert np.array_equal(a3, a2) and np.array_equal(l3, l2)
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["fastkernel_gram_Q5_D2_R2", "fastkernel_gram_Q5_D24_R8", "fastkernel_gram_Q3_D7_R4"])
+def test_hip_factor_vs_reference_derived_gram(name):
+    """Rows a3-a8 pinned end to end on the DEVICE: Gram matrices assembled from the reference's own Python factors
+    (fastkernel.py, numpy's pi) + noise -> scipy Cholesky; the HIP path must reproduce nlml, alpha and L^-1 of that K."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    Q, D, R, N = int(g["Q"]), int(g["D"]), int(g["R"]), int(g["N"])
+    m, t, y, th = g["meta"], g["t"], g["y"], g["theta"]
+    K = g["K"] + np.diag(np.exp(2 * th[m]))
+    L = sla.cholesky(K, lower=True)
+    yy = y.astype(np.float64)
+    alpha_ref = sla.cho_solve((L, True), yy)
+    nlml_ref = 0.5 * yy @ alpha_ref + np.log(np.diag(L)).sum() + 0.5 * N * np.log(2 * np.pi)
+    linv_ref = sla.solve_triangular(L, np.eye(N), lower=True)
+    ctx = make_ctx(7, Q, D, R, [(m, t, y)])
+    ctx.set_pi(np.pi)
+    nl, _, st = ctx.nlml_grad([0], th[None, :], False, keep_factor=True)
+    assert st[0] == 0
+    assert abs(nl[0] - nlml_ref) <= 1e-10 * abs(nlml_ref)
+    alpha, linv, _ = ctx.get_factor(0, N)
+    np.testing.assert_allclose(alpha, alpha_ref, rtol=2e-6, atol=1e-6 * np.abs(alpha_ref).max())
+    np.testing.assert_allclose(linv, linv_ref, rtol=2e-6, atol=1e-6 * np.abs(linv_ref).max())
+    ctx.close()
+
+
+def test_packed_upload_equals_single_uploads():
+    D, Q, R = 4, 3, 2
+    ns = [1, 64, 130, 17, 200, 2]
+    pts = [synth.patient(81, p, D, n, interleave=(p % 2 == 1)) for p, n in enumerate(ns)]
+    th = np.stack([synth.theta(81, p, 7, Q, D, R) for p in range(len(ns))])
+    a = make_ctx(7, Q, D, R, pts)
+    b = medgp_amd.Context(7, Q, D, R)
+    b.reserve(len(ns), max(ns), len(ns))
+    b.set_patients(np.arange(len(ns))[::-1].copy(), pts[::-1])       # arbitrary slot order in one call
+    ra = a.nlml_grad(np.arange(len(ns)), th, True)
+    rb = b.nlml_grad(np.arange(len(ns)), th, True)
+    for x, z in zip(ra, rb):
+        assert np.array_equal(x, z, equal_nan=True)
+    assert ra[2][0] == -1 and ra[2][5] == -1 and np.all(ra[2][1:5] == 0)
+    with pytest.raises(medgp_amd.MedgpError):
+        b.set_patients([0, 9], pts[:2])
+    a.close(); b.close()
