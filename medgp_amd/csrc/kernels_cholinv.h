@@ -293,6 +293,86 @@ __device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X,
     diag_factor_wave_body(D, X, dv, fail, logdet, lane);
 }
 
+// Cholesky of the 64x64 block D and its inverse X on FOUR waves (all waves of the workgroup call it; waves >= 4 only take part
+// in the barriers).  Same tile algebra as diag_factor_wave_body; the serial chain is the four register-resident 16x16
+// factorisations (diag16) on wave 0, everything else runs beside it:
+//   phase A(t): panel tiles L(s,t) = D(s,t) X(t,t)^T, one per wave                                     | barrier
+//   phase B(t): wave 0: trailing tile (t+1,t+1), then diag16(t+1) right away (its own data, no barrier);
+//               waves 1-3: the other trailing tiles D(s,u) -= L(s,t) L(u,t)^T, then the finished rows of the inverse
+//               X(t, 0..t-1) = -X(t,t) sum_u L(t,u) X(u,.)  (needs only diagonal inverses <= t)       | barrier
+//   tail      : X(3, 0..2) on three waves, zero tiles, log det.
+// Critical path: 4 diag16 + 3 (panel + one trailing tile + 2 barriers) + one inverse row.
+__device__ __forceinline__ void inv_row_tiles(double *D, double *X, int s2, int t, int li, int g) {
+    // X(s2,t) = -X(s2,s2) P,  P = sum_{u=t}^{s2-1} L(s2,u) X(u,t)
+#define TD(s, t) (D + (16 * (s)) * CI_S + 16 * (t))
+#define TX(s, t) (X + (16 * (s)) * CI_S + 16 * (t))
+    v4d pp = {0.0, 0.0, 0.0, 0.0};
+    for (int u = t; u < s2; u++) pp = tile_mm<false, false>(TD(s2, u), TX(u, t), pp, li, g);
+    v4d xo = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; r++) xo = __builtin_amdgcn_mfma_f64_16x16x4f64(-TX(s2, s2)[li * CI_S + 4 * r + g], pp[r], xo, 0, 0, 0);
+    tile_st(TX(s2, t), xo, li, g);
+}
+__device__ __forceinline__ void trail_tile(double *D, int s2, int u, int t, int li, int g) {
+    v4d c = tile_ld(TD(s2, u), li, g);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-TD(s2, t)[li * CI_S + 4 * k + g], TD(u, t)[li * CI_S + 4 * k + g], c, 0, 0, 0);
+    tile_st(TD(s2, u), c, li, g);
+}
+__device__ __attribute__((noinline)) void diag_factor_wg(double *D, double *X, double *dv, int *fail, double *logdet, int wave, int lane) {
+    const int li = lane & 15, g = lane >> 4;
+    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    if (wave == 0) {
+        if (!diag16(TD(0, 0), TX(0, 0), dv, lane)) { if (lane == 0) *fail = 1; }
+    }
+    __syncthreads();
+    if (*fail) return;
+#pragma unroll 1
+    for (int t = 0; t < 3; t++) {
+        // ---- phase A: panel below the diagonal tile
+        if (wave < 3 - t) {
+            const int s2 = t + 1 + wave;
+            v4d lt = tile_mm<false, true>(TD(s2, t), TX(t, t), zero4, li, g);   // D(s,t) X(t,t)^T
+            tile_st(TD(s2, t), lt, li, g);
+        }
+        __syncthreads();
+        // ---- phase B
+        if (wave == 0) {
+            trail_tile(D, t + 1, t + 1, t, li, g);
+            __builtin_amdgcn_wave_barrier();
+            if (!diag16(TD(t + 1, t + 1), TX(t + 1, t + 1), dv + 16 * (t + 1), lane)) { if (lane == 0) *fail = 1; }
+        } else if (wave < 4) {
+            // remaining trailing tiles (s,u), t+1 <= u <= s <= 3, (s,u) != (t+1,t+1): dealt round-robin to waves 1..3
+            int e = 0;
+            for (int s2 = t + 1; s2 < 4; s2++)
+                for (int u = t + 1; u <= s2; u++) {
+                    if (s2 == t + 1 && u == t + 1) continue;
+                    if (e % 3 == wave - 1) trail_tile(D, s2, u, t, li, g);
+                    e++;
+                }
+            // finished inverse row t (t >= 1): tiles X(t, 0..t-1)
+            if (t >= 1 && wave - 1 < t) inv_row_tiles(D, X, t, wave - 1, li, g);
+        }
+        __syncthreads();
+        if (*fail) return;
+    }
+    // ---- tail: inverse rows 3 (and row 2 was done in phase B(2))
+    if (wave < 3) inv_row_tiles(D, X, 3, wave, li, g);
+    else if (wave == 3) {
+#pragma unroll
+        for (int t = 1; t < 4; t++)
+            for (int s2 = 0; s2 < t; s2++) tile_st(TX(s2, t), zero4, li, g);   // strictly-upper tiles of X are zero
+        double lg = log(dv[lane]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
+        if (lane == 0) *logdet += lg;
+    }
+    __syncthreads();
+#undef TD
+#undef TX
+}
+
 // ---- one factorisation attempt; returns false if a pivot failed ---------------------------------------------------
 // Split of a step's row blocks over the waves: a pass covers NW block slots (M blocks first, then the U blocks by
 // ascending row block) and wave w owns the 16-row unit (w & 3) of FOUR slots, so all waves carry the same history
@@ -527,8 +607,12 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 if (wave == NW - 1) sm.zacc[lane] = zsum;
                 __syncthreads();
                 STAMP(0);   // wait for the slowest GEMM wave (folded into 0)
+#ifdef CI_DIAG_ONE_WAVE
+                if (wave == 0) diag_factor_wave(&sm.Dk[0][0], &sm.Xk[0][0], sm.rhs, &sm.fail, &sm.logdet, lane);
+#else
+                diag_factor_wg(&sm.Dk[0][0], &sm.Xk[0][0], sm.rhs, &sm.fail, &sm.logdet, wave, lane);
+#endif
                 if (wave == 0) {
-                    diag_factor_wave(&sm.Dk[0][0], &sm.Xk[0][0], sm.rhs, &sm.fail, &sm.logdet, lane);
                     STAMP(3);   // diagonal factor
                     if (!sm.fail) {
                         // z_k = L_kk^-1 (y_k - zacc).  Xk has exact zeros above the diagonal, so the fixed-length loops
@@ -657,12 +741,15 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 
 // grid = nbatch, block = NW * 64.  NW = 8: one workgroup per CU (lowest latency per patient);
 // NW = 4: two workgroups per CU, the serial diagonal-block phase of one overlaps the MFMA phase of the other.
+// only_small = 1: entries with more than one 64-block are left to the multi-CU schedule (kernels_cholinv_la.h); which
+// schedule factors an entry is a function of its own n and of how many LARGE entries the call holds, never of its batch-mates' sizes
 template <int NW, int UPW>
-__global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int want_inv) {
+__global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int want_inv, int only_small) {
     constexpr int NT = NW * 64;
     __shared__ CholInvSmem<NW, UPW> sm;
     const int b = blockIdx.x, tid = threadIdx.x;
     if (L.status[b] < 0) return;
+    if (only_small && L.pn[L.bslot[b]] > 64) return;
     // loaded values the whole workgroup agrees on: pin them to scalar registers, otherwise every quantity derived from
     // n (block counts, slot tables, row bases) lives in VGPRs across the MFMA loop and its branches run on exec masks
     const int slot = __builtin_amdgcn_readfirstlane(L.bslot[b]);

@@ -1,0 +1,395 @@
+// kernels_cholinv_la.h -- look-ahead multi-CU factorisation for FEW, LARGE patients (BASELINE configs 3 and 5: one
+// patient with N = 2048 / 4096).  Replaces LAPACKE_spotrf + spotrs + strtri of the reference
+// (ref: inference/c_inference_exact.cpp:96-143) with the same recurrence as k_cholinv (kernels_cholinv.h): the
+// left-looking panel recurrence on T = [K; I; y^T], whose rows turn into L, U = L^-T and z^T = (L^-1 y)^T.
+//
+// Why a second schedule.  The first multi-CU version ran two launches per 64-wide step and gave the WHOLE history product of
+// a 64-row block (64 x 64 x 64k flops) to one workgroup: nb + k workgroups on 256 CUs, and the diagonal block's product
+// sat in front of the serial 64x64 factorisation on the critical path (N = 2048: 3.4 ms, 3 % of the fp64 peak).  Here
+//   * ONE launch per step k (k_la_step) holds three kinds of workgroups that do not depend on each other inside the launch:
+//     D  (1 per patient)   diagonal chain: L[C_k+1, C_k] = P X_k^T, the two newest rank-64 terms of the NEXT diagonal
+//                          block, its 64x64 factorisation on four waves (diag_factor_wg) -> X_k+1.  The chain never waits
+//                          for a deep product: everything older than two panels was summed ahead of time by L tasks.
+//     F  (1 per row block) finish panel k: row_r[C_k] = P_r,k X_k^T, then build the pre-solve block of panel k+1:
+//                          P_r,k+1 = init - sum(partials) - row_r[C_k-1] L[C_k+1,C_k-1]^T - row_r[C_k] L[C_k+1,C_k]^T.
+//     L  (look-ahead)      for panel k+2 and every row block: partial sums over history slices of LA_SLICE panels
+//                          (columns <= C_k-1, all final before the launch) into a scratch slab -- split-K over as many
+//                          workgroups as the chip has CUs, summed later in a fixed order (bitwise reproducible).
+//   * the serial work per step is the diagonal chain only: about 40 + 168 MFMAs per wave + diag_factor_wg.
+// Row blocks of a step: M_i (K rows, i > k), U_rho (inverse rows, rho <= k, only with want_mode bit 0), Y (the y^T row, a
+// 64-row block of which row 0 is real: z comes out of the same recurrence as everything else).
+// The reference's jitter loop (ref: c_inference_exact.cpp:99-108) is driven from the host as before: a failed pivot marks
+// the problem (status -2), later launches skip it, the host bumps its jitter count and re-runs assembly + factorisation.
+#pragma once
+#include "kernels_cholinv.h"
+
+#define LA_KC 32          // history columns staged per barrier
+#define LA_THREADS 256
+#define LA_SLICE 4        // panels (64 columns each) per look-ahead slice
+#define LA_S 66           // LDS row stride of the 64x64 operand tiles
+
+struct LaArgs {
+    double *ybuf;         // [batch][64][ldn]   the Y row block (row 0 = y^T -> z^T)
+    double *part;         // [batch][2][rows][maxslice][64*64]   look-ahead partial sums, indexed by panel parity
+    double *xk2;          // [batch][2][64*64]  X_k = L_kk^-1, indexed by panel parity
+    double *pnx;          // [batch][2][64*64]  copy of the pre-solve block P_k+1,k (row-major), indexed by panel parity: every
+                          //                    workgroup of step k re-derives L[C_k+1,C_k] from it while D overwrites the
+                          //                    in-place block with the solved values
+    int nbmax;            // 64-blocks of the largest patient of the batch
+    int maxslice;         // slices per row block the scratch is dimensioned for
+    int rows;             // row blocks the scratch is dimensioned for (2 nbmax + 1)
+};
+
+// row block index inside the scratch: M_i -> i, U_rho -> nbmax + rho, Y -> 2 nbmax
+struct LaRow {
+    int kind;             // 0 = M, 1 = U, 2 = Y
+    int blk;              // i or rho
+};
+
+struct LaSmem {
+    union {
+        double Bs[2][64][LA_KC + 2];     // staged shared operand of the history GEMM
+        double Xs[64][LA_S];             // X_k (trsm), later D_k+1 (factor input)
+    };
+    double Ls[64][LA_S];                 // L[C_k+1, C_k] (B operand of the newest rank-64 term), later X_k+1 (factor output)
+    double dv[64];
+    double logdet;
+    int fail;
+};
+static_assert(sizeof(LaSmem) <= 80 * 1024, "two workgroups per CU");
+static_assert(sizeof(double) * 2 * 64 * (LA_KC + 2) <= sizeof(double) * 64 * LA_S + 2048, "Bs and Xs share storage");
+
+__device__ __forceinline__ double *la_row_base(const MedgpDev &L, const LaArgs &A, int b, LaRow r) {
+    const size_t ld = L.ldn;
+    if (r.kind == 0) return L.Kmat + (size_t)b * ld * ld + (size_t)(64 * r.blk) * ld;
+    if (r.kind == 1) return L.Linv + (size_t)b * ld * ld + (size_t)(64 * r.blk) * ld;
+    return A.ybuf + (size_t)b * 64 * ld;
+}
+__device__ __forceinline__ int la_row_index(const LaArgs &A, LaRow r) {
+    return r.kind == 0 ? r.blk : (r.kind == 1 ? A.nbmax + r.blk : 2 * A.nbmax);
+}
+__device__ __forceinline__ double *la_part(const LaArgs &A, int b, int parity, LaRow r, int slice) {
+    return A.part + ((((size_t)b * 2 + parity) * A.rows + la_row_index(A, r)) * A.maxslice + slice) * 4096;
+}
+// first history panel of a row block (U_rho starts at its own diagonal block)
+__device__ __forceinline__ int la_first_panel(LaRow r) { return r.kind == 1 ? r.blk : 0; }
+
+// acc[ct] += rows(row0 + 16 w ..) of Hist[:, 64 j0 .. 64 j1) times rows 64 c .. of Lb[:, same columns]^T   (the k_ci_panel loop)
+// acc[ct][r] <-> (row 16 w + 4 r + g, column 16 ct + li) of the 64x64 product.
+__device__ __forceinline__ void la_gemm(const double *Hist, const double *Bpanel, int ld, int j0, int j1, v4d (&acc)[4],
+                                        LaSmem &sm, int tid, int w, int li, int g) {
+    const int nch = (64 * (j1 - j0)) / LA_KC;
+    if (nch <= 0) return;
+    const int kstart = 64 * j0;
+    const double *Arow = Hist + (size_t)(16 * w + li) * ld + kstart + 2 * g;
+    const int srow = tid >> 2, scg = (tid & 3) * 8;
+    const double *Bsrc = Bpanel + (size_t)srow * ld + kstart + scg;
+    v2d bst[4], an[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) bst[u] = *(const v2d *)(Bsrc + 2 * u);
+#pragma unroll
+    for (int h = 0; h < 4; h++) an[h] = *(const v2d *)(Arow + 8 * h);
+#pragma unroll
+    for (int u = 0; u < 4; u++) *(v2d *)&sm.Bs[0][srow][scg + 2 * u] = bst[u];
+    __syncthreads();
+    for (int c = 0; c < nch; c++) {
+        const int buf = c & 1;
+        v2d ac[4];
+#pragma unroll
+        for (int h = 0; h < 4; h++) ac[h] = an[h];
+        if (c + 1 < nch) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) bst[u] = *(const v2d *)(Bsrc + (c + 1) * LA_KC + 2 * u);
+#pragma unroll
+            for (int h = 0; h < 4; h++) an[h] = *(const v2d *)(Arow + (c + 1) * LA_KC + 8 * h);
+        }
+#pragma unroll
+        for (int h = 0; h < 4; h++)
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++) {
+                const v2d bf = *(const v2d *)&sm.Bs[buf][16 * ct + li][8 * h + 2 * g];
+#pragma unroll
+                for (int s = 0; s < 2; s++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[h][s], bf[s], acc[ct], 0, 0, 0);
+            }
+        if (c + 1 < nch) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) *(v2d *)&sm.Bs[buf ^ 1][srow][scg + 2 * u] = bst[u];
+        }
+        __syncthreads();
+    }
+}
+
+// out^T tiles of  block * X^T :  o[ct][r] = out(row li of the wave's 16 rows, column 16 ct + 4 r + g); X in LDS (lower).
+// val[cp][r] = block(row li, column 16 cp + 4 r + g)
+__device__ __forceinline__ void la_trsm(const double (*Xs)[LA_S], const v4d (&val)[4], v4d (&o)[4], int li, int g) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) {
+        o[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int cp = 0; cp <= ct; cp++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                o[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[16 * ct + li][16 * cp + 4 * r + g], val[cp][r], o[ct], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void la_load_t(const double *blk, int ld, v4d (&val)[4], int li, int g) {
+#pragma unroll
+    for (int cp = 0; cp < 4; cp++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) val[cp][r] = blk[(size_t)li * ld + 16 * cp + 4 * r + g];
+}
+__device__ __forceinline__ void la_store_t(double *blk, int ld, const v4d (&o)[4], int li, int g) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) blk[(size_t)li * ld + 16 * ct + 4 * r + g] = o[ct][r];
+}
+
+// ---- prologue: Y row block <- [y^T; 0], diagonal block 0 factored -> X_0 ------------------------------------------------
+// grid = (nbatch, 1 + nbmax): y = 0 is the diagonal role, y >= 1 initialise 64 columns of the Y block each (y = 1 also
+// seeds the copy of the pre-solve block P_1,0 = K[block 1][C_0])
+__global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A, int want_mode) {
+    __shared__ LaSmem sm;
+    const int b = blockIdx.x;
+    if (L.status[b] < 0) return;
+    const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
+    if (nb < 2) return;   // single-block entries are factored by k_cholinv (see its only_small switch)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (blockIdx.y >= 1) {
+        const int cb = blockIdx.y - 1;
+        if (cb >= nb) return;
+        double *Y = A.ybuf + (size_t)b * 64 * ld;
+        const double *y = L.py + (size_t)slot * ld;
+        for (int e = tid; e < 64 * 64; e += LA_THREADS) {
+            const int rr = e >> 6, cc = 64 * cb + (e & 63);
+            Y[(size_t)rr * ld + cc] = (rr == 0 && cc < n) ? y[cc] : 0.0;
+        }
+        if (cb == 0 && nb > 1) {
+            const double *K10 = L.Kmat + (size_t)b * ld * ld + (size_t)64 * ld;
+            double *Pn = A.pnx + ((size_t)b * 2 + 0) * 4096;
+            for (int e = tid; e < 64 * 64; e += LA_THREADS) Pn[e] = K10[(size_t)(e >> 6) * ld + (e & 63)];
+        }
+        return;
+    }
+    double *Lb = L.Kmat + (size_t)b * ld * ld, *Ub = L.Linv + (size_t)b * ld * ld;
+    if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
+    for (int e = tid; e < 64 * 64; e += LA_THREADS) { const int rr = e >> 6, cc = e & 63; sm.Xs[rr][cc] = (cc <= rr) ? Lb[(size_t)rr * ld + cc] : 0.0; }
+    __syncthreads();
+    diag_factor_wg(&sm.Xs[0][0], &sm.Ls[0][0], sm.dv, &sm.fail, &sm.logdet, w, lane);
+    __syncthreads();
+    if (sm.fail) { if (tid == 0) L.status[b] = -2; return; }
+    double *Xg = A.xk2 + ((size_t)b * 2 + 0) * 4096;
+    for (int e = tid; e < 64 * 64; e += LA_THREADS) {
+        const int rr = e >> 6, cc = e & 63;
+        if (cc <= rr) Lb[(size_t)rr * ld + cc] = sm.Xs[rr][cc];
+        if (want_mode) Ub[(size_t)rr * ld + cc] = (cc >= rr) ? sm.Ls[cc][rr] : 0.0;
+        Xg[e] = sm.Ls[rr][cc];
+    }
+    if (tid == 0) L.scal[b * 4 + 0] = sm.logdet;
+}
+
+// ---- one step ----------------------------------------------------------------------------------------------------------
+// grid = (nbatch, ntask): task 0 = D, tasks 1 .. nF = F (row blocks), then L tasks (row block x slice).
+// Row-block enumeration for F at step k (panel k is finished, panel k+1 prepared):
+//   M_i, i = k+2 .. nb-1   |  U_rho, rho = 0 .. k (inverse only)  |  Y
+// and for L at step k (partials of panel k+2 over history panels <= k-1; rows that exist in panel k+2 and have such history):
+//   M_i, i = k+2 .. nb-1   |  U_rho, rho = 0 .. k-1 (inverse only) |  Y       x  slice index
+__global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A, int k, int want_mode) {
+    __shared__ LaSmem sm;
+    const int b = blockIdx.x;
+    if (L.status[b] < 0) return;
+    const int slot = __builtin_amdgcn_readfirstlane(L.bslot[b]);
+    const int n = __builtin_amdgcn_readfirstlane(L.pn[slot]);
+    const int ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
+    if (k >= nb || nb < 2) return;
+    const int want_inv = want_mode & 1;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *Lb = L.Kmat + (size_t)b * ld * ld, *Ub = L.Linv + (size_t)b * ld * ld;
+    const int c0 = 64 * k, c1 = 64 * (k + 1);
+    const bool has_next = (k + 1 < nb);
+    int task = blockIdx.y;
+    // the task lists are laid out for the largest patient of the batch (A.nbmax)
+    const int nM_F = A.nbmax - (k + 2) > 0 ? A.nbmax - (k + 2) : 0;
+    const int nU_F = want_inv ? k + 1 : 0;
+    const int nF = nM_F + nU_F + 1;
+    LaRow row;
+    int role, slice = 0;
+    if (task == 0) { role = 0; row.kind = 0; row.blk = k + 1; }
+    else if (task <= nF) {
+        role = 1;
+        int t = task - 1;
+        if (t < nM_F) { row.kind = 0; row.blk = k + 2 + t; }
+        else if (t < nM_F + nU_F) { row.kind = 1; row.blk = t - nM_F; }
+        else { row.kind = 2; row.blk = 0; }
+    } else {
+        role = 2;
+        int t = task - 1 - nF;
+        slice = t % A.maxslice;
+        t /= A.maxslice;
+        const int nU_L = want_inv ? k : 0;
+        if (t < nM_F) { row.kind = 0; row.blk = k + 2 + t; }
+        else if (t < nM_F + nU_L) { row.kind = 1; row.blk = t - nM_F; }
+        else if (t == nM_F + nU_L) { row.kind = 2; row.blk = 0; }
+        else return;
+    }
+    if (row.kind == 0 && row.blk >= nb && !(role == 0)) return;   // beyond this patient's blocks
+    double *Rb = la_row_base(L, A, b, row);
+
+    // ============================== L: look-ahead partial sum of panel k+2 =============================================
+    if (role == 2) {
+        if (k + 2 >= nb) return;
+        const int j0 = la_first_panel(row) + LA_SLICE * slice;
+        int j1 = j0 + LA_SLICE;
+        if (j1 > k) j1 = k;                       // history panels <= k-1
+        if (j0 >= j1) return;
+        v4d acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) acc[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
+        la_gemm(Rb, Lb + (size_t)(64 * (k + 2)) * ld, ld, j0, j1, acc, sm, tid, w, li, g);
+        double *P = la_part(A, b, (k + 2) & 1, row, slice) + (size_t)w * 1024 + lane;
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) P[(ct * 4 + r) * 64] = acc[ct][r];
+        return;
+    }
+
+    // ============================== D and F ============================================================================
+    const double *Xg = A.xk2 + ((size_t)b * 2 + (k & 1)) * 4096;
+    const bool is_D = (role == 0);
+    if (is_D && !has_next) return;                // the last panel has no next diagonal block
+    // ---- (1) pre-solve block of panel k+1: acc = -init + partials + term of panel k-1     (non-transposed tiles)
+    v4d acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) acc[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int jf = la_first_panel(row);
+    if (has_next) {
+        if (row.kind != 1) {   // K rows and the y row carry their own initial values in place; U rows start from zero
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[ct][r] = -Rb[(size_t)(16 * w + 4 * r + g) * ld + c1 + 16 * ct + li];
+        }
+        // partial sums over history panels jf .. k-2, written by the L tasks of the previous launch
+        const int hist_end = k - 1;               // panels jf .. hist_end-1
+        for (int s = 0; jf + LA_SLICE * s < hist_end; s++) {
+            const double *P = la_part(A, b, (k + 1) & 1, row, s) + (size_t)w * 1024 + lane;
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[ct][r] += P[(ct * 4 + r) * 64];
+        }
+        // panel k-1 (final since the previous launch)
+        if (k >= 1 && jf <= k - 1) la_gemm(Rb, Lb + (size_t)c1 * ld, ld, k - 1, k, acc, sm, tid, w, li, g);
+    }
+    // ---- (2) X_k -> LDS (Bs is dead: la_gemm ends with a barrier)
+    for (int e = tid; e < 64 * 64; e += LA_THREADS) sm.Xs[e >> 6][e & 63] = Xg[e];
+    __syncthreads();
+    // ---- (3) L[C_k+1, C_k] = P_k+1,k X_k^T for the wave's 16 rows of block k+1 -> LDS (and, D only, to memory)
+    v4d o[4];
+    if (has_next) {
+        v4d val[4];
+        la_load_t(A.pnx + ((size_t)b * 2 + (k & 1)) * 4096 + (size_t)(16 * w) * 64, 64, val, li, g);
+        la_trsm(sm.Xs, val, o, li, g);
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) sm.Ls[16 * w + li][16 * ct + 4 * r + g] = o[ct][r];
+        if (is_D) la_store_t(Lb + (size_t)(c1 + 16 * w) * ld + c0, ld, o, li, g);   // final L[C_k+1, C_k]
+    }
+    // ---- (4) own rows of panel k: row_r[C_k] = P_r,k X_k^T   (D: that is the block above, already in o;  U_k: the
+    //      diagonal block U_kk itself, final since the previous launch)
+    if (!is_D) {
+        double *blk = Rb + (size_t)(16 * w) * ld + c0;
+        if (row.kind == 1 && row.blk == k) la_load_t(blk, ld, o, li, g);
+        else {
+            v4d val[4];
+            la_load_t(blk, ld, val, li, g);
+            la_trsm(sm.Xs, val, o, li, g);
+            la_store_t(blk, ld, o, li, g);
+        }
+    }
+    if (!has_next) return;
+    __syncthreads();   // Ls complete
+    // ---- (5) newest rank-64 term: acc += row_r[C_k] L[C_k+1,C_k]^T, straight from the trsm registers (A operand)
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double a = o[ct][r];
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++)
+                acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sm.Ls[16 * cb + li][16 * ct + 4 * r + g], acc[cb], 0, 0, 0);
+        }
+    if (!is_D) {
+        // pre-solve block of panel k+1 (value = -acc), stored in place
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) Rb[(size_t)(16 * w + 4 * r + g) * ld + c1 + 16 * ct + li] = -acc[ct][r];
+        if (row.kind == 0 && row.blk == k + 2) {   // next step's P_k+2,k+1: everybody reads this copy
+            double *Pn = A.pnx + ((size_t)b * 2 + ((k + 1) & 1)) * 4096;
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) Pn[(16 * w + 4 * r + g) * 64 + 16 * ct + li] = -acc[ct][r];
+        }
+        return;
+    }
+    // ---- (6) D: factor the next diagonal block
+    __syncthreads();   // every wave is done reading Xs / Ls
+    if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) sm.Xs[16 * w + 4 * r + g][16 * ct + li] = -acc[ct][r];
+    __syncthreads();
+    diag_factor_wg(&sm.Xs[0][0], &sm.Ls[0][0], sm.dv, &sm.fail, &sm.logdet, w, lane);
+    __syncthreads();
+    if (sm.fail) { if (tid == 0) L.status[b] = -2; return; }
+    double *Xn = A.xk2 + ((size_t)b * 2 + ((k + 1) & 1)) * 4096;
+    for (int e = tid; e < 64 * 64; e += LA_THREADS) {
+        const int rr = e >> 6, cc = e & 63;
+        if (cc <= rr) Lb[(size_t)(c1 + rr) * ld + c1 + cc] = sm.Xs[rr][cc];
+        if (want_mode) Ub[(size_t)(c1 + rr) * ld + c1 + cc] = (cc >= rr) ? sm.Ls[cc][rr] : 0.0;
+        Xn[e] = sm.Ls[rr][cc];
+    }
+    if (tid == 0) L.scal[b * 4 + 0] += sm.logdet;   // steps are ordered launches: fixed summation order
+}
+
+// ---- epilogue of the factorisation: z, quad = z^T z, alpha = U z, status = jitter count -----------------------------------
+// grid = (nbatch, nbmax): block y owns rows 64 y .. of alpha; block 0 also publishes quad and the status
+__global__ void __launch_bounds__(256) k_la_finish(MedgpDev L, LaArgs A, int want_mode) {
+    __shared__ double red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (L.status[b] < 0) return;
+    const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
+    const int rb = blockIdx.y;
+    if (rb >= nb || nb < 2) return;
+    const double *zrow = A.ybuf + (size_t)b * 64 * ld;   // row 0 of the Y block
+    if (want_mode & 1) {
+        const double *U = L.Linv + (size_t)b * ld * ld;
+        for (int r = w; r < 64; r += 4) {       // alpha_i = sum_{c >= 64 rb} U[i][c] z[c]  (zeros left of the diagonal inside the block)
+            const int i = 64 * rb + r;
+            const double *ur = U + (size_t)i * ld;
+            double s = 0.0;
+            for (int c = 64 * rb + lane; c < npad; c += 64) s += ur[c] * zrow[c];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            if (lane == 0) L.alpha[(size_t)b * ld + i] = s;
+        }
+    }
+    for (int c = 64 * rb + tid; c < 64 * rb + 64; c += 256) L.z[(size_t)b * ld + c] = zrow[c];
+    if (rb == 0) {
+        double s = 0.0;
+        for (int i = tid; i < npad; i += 256) s += zrow[i] * zrow[i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if (lane == 0) red[w] = s;
+        __syncthreads();
+        if (tid == 0) {
+            L.scal[b * 4 + 1] = red[0] + red[1] + red[2] + red[3];
+            L.status[b] = L.jit[b];
+        }
+    }
+}

@@ -6,6 +6,7 @@
 #include "kernels_v0.h"
 #include "kernels_cholinv.h"
 #include "kernels_cholinv_mc.h"
+#include "kernels_cholinv_la.h"
 #include "kernels_assemble.h"
 #include "kernels_wgrad.h"
 #include "kernels_io.h"
@@ -21,8 +22,8 @@
 
 namespace {
 
-enum KernelId { KID_PREP = 0, KID_ASSEMBLE, KID_POTRF, KID_TRTRI, KID_CHOLINV, KID_CI_PANEL, KID_CI_TRSM, KID_LAUUM, KID_GRADBINS, KID_WGRAD, KID_EPILOGUE, KID_PREDICT, KID_COUNT };
-const char *const kKernelNames[KID_COUNT] = {"k_prep", "k_assemble", "k_potrf", "k_trtri", "k_cholinv", "k_ci_panel", "k_ci_trsm", "k_lauum", "k_gradbins", "k_wgrad", "k_epilogue", "k_predict"};
+enum KernelId { KID_PREP = 0, KID_ASSEMBLE, KID_POTRF, KID_TRTRI, KID_CHOLINV, KID_CI_PANEL, KID_CI_TRSM, KID_LA_STEP, KID_LA_AUX, KID_LAUUM, KID_GRADBINS, KID_WGRAD, KID_EPILOGUE, KID_PREDICT, KID_COUNT };
+const char *const kKernelNames[KID_COUNT] = {"k_prep", "k_assemble", "k_potrf", "k_trtri", "k_cholinv", "k_ci_panel", "k_ci_trsm", "k_la_step", "k_la_aux", "k_lauum", "k_gradbins", "k_wgrad", "k_epilogue", "k_predict"};
 
 thread_local std::string g_create_error;   // last medgp_create error of the calling thread
 
@@ -58,6 +59,10 @@ struct medgp_ctx {
     size_t stage_cap = 0;
     hipEvent_t ev_stage = nullptr;
     bool stage_pending = false;
+    // scratch of the look-ahead multi-CU factorisation (kernels_cholinv_la.h), grown on demand
+    double *d_la_part = nullptr, *d_la_small = nullptr;
+    size_t la_part_cap = 0, la_small_cap = 0;
+    int mc_old = 0;           // MEDGP_MC_OLD=1: the first multi-CU schedule (two launches per step), kept for A/B runs
     int *d_one_slot = nullptr;       // single-entry slot table for the caller-order re-factorisation of medgp_get_factor
     // predict scratch
     double *d_t2 = nullptr, *d_ks = nullptr;
@@ -184,10 +189,42 @@ int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bo
 
 inline int tri(int n) { return n * (n + 1) / 2; }
 
+// scratch of the look-ahead factorisation for `nbatch` entries of at most `nbmax` 64-blocks (freed by free_all)
+int ensure_la(medgp_ctx *c, int nbatch, int nbmax, LaArgs *out) {
+    LaArgs A{};
+    A.nbmax = nbmax;
+    A.maxslice = (nbmax + LA_SLICE - 1) / LA_SLICE;
+    A.rows = 2 * nbmax + 1;
+    const size_t need_part = (size_t)nbatch * 2 * A.rows * A.maxslice * 4096;
+    const size_t need_small = (size_t)nbatch * (64 * (size_t)c->ldn + 4 * 4096);
+    auto grow = [&](double **p, size_t *cap, size_t need) -> int {
+        if (need <= *cap) return MEDGP_OK;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (*p) {
+            (void)hipFree(*p);
+            c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), (void *)*p), c->allocs.end());
+            *p = nullptr; *cap = 0;
+        }
+        int rc = dalloc(c, p, need);
+        if (rc) return rc;
+        *cap = need;
+        return MEDGP_OK;
+    };
+    int rc;
+    if ((rc = grow(&c->d_la_part, &c->la_part_cap, need_part))) return rc;
+    if ((rc = grow(&c->d_la_small, &c->la_small_cap, need_small))) return rc;
+    A.part = c->d_la_part;
+    A.ybuf = c->d_la_small;
+    A.xk2 = c->d_la_small + (size_t)nbatch * 64 * c->ldn;
+    A.pnx = A.xk2 + (size_t)nbatch * 2 * 4096;
+    *out = A;
+    return MEDGP_OK;
+}
+
 // one kernel chain for the batch entries described by L (possibly a shifted view of c->dev) on `stream`
 int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nbatch, int max_n, const double *theta_dev,
                      int flag_grad, bool need_inverse, int min_n, double *nlml_dev, double *grad_dev, int32_t *status_dev,
-                     bool store_ukk = false) {
+                     bool store_ukk, const int *entry_n) {
     const int nt64 = medgp_roundup(std::max(max_n, 1), 64) / 64;
     { Launcher l(c, KID_PREP, stream); hipLaunchKernelGGL(k_prep, dim3(nbatch), dim3(256), 0, stream, L, theta_dev, min_n); }
     auto launch_assemble = [&]() {
@@ -222,17 +259,40 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         // from the host here: a failed pivot leaves status -2; the failed problems restart with one more noise addition
         // (L.jit), finished ones are recomputed identically (same inputs, same order of operations).
         std::vector<int> hst(nbatch), hjit(nbatch, 0), nst(nbatch);
+        // which entries the multi-CU schedule factors: more than one 64-block (host mirror of the patient sizes)
+        std::vector<uint8_t> big(nbatch, 1);
+        bool any_small = false;
+        for (int bb = 0; bb < nbatch; bb++) {
+            big[bb] = entry_n[bb] > 64;
+            any_small = any_small || !big[bb];
+        }
+        LaArgs la{};
+        if (!c->mc_old) { int rc = ensure_la(c, nbatch, nt64, &la); if (rc) return rc; }
         for (int attempt = 0;; attempt++) {
             launch_assemble();
-            for (int k = 0; k < nt64; k++) {
-                { Launcher l(c, KID_CI_PANEL, stream); hipLaunchKernelGGL(k_ci_panel, dim3(nbatch, nt64), dim3(MC_THREADS), 0, stream, L, k, want_mode); }
-                if (nt64 > 1) { Launcher l(c, KID_CI_TRSM, stream); hipLaunchKernelGGL(k_ci_trsm, dim3(nt64 - 1, nbatch), dim3(MC_THREADS), 0, stream, L, k, want_mode); }
+            if (c->mc_old) {
+                for (int k = 0; k < nt64; k++) {
+                    { Launcher l(c, KID_CI_PANEL, stream); hipLaunchKernelGGL(k_ci_panel, dim3(nbatch, nt64), dim3(MC_THREADS), 0, stream, L, k, want_mode); }
+                    if (nt64 > 1) { Launcher l(c, KID_CI_TRSM, stream); hipLaunchKernelGGL(k_ci_trsm, dim3(nt64 - 1, nbatch), dim3(MC_THREADS), 0, stream, L, k, want_mode); }
+                }
+                hipLaunchKernelGGL(k_ci_finish, dim3(nbatch), dim3(256), 0, stream, L);
+            } else {
+                // entries of a single 64-block: one workgroup each (the same kernel, hence the same bits, as in any other call)
+                if (any_small) { Launcher l(c, KID_CHOLINV, stream); hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, want_mode, 1); }
+                // look-ahead schedule: one launch per 64-wide step (kernels_cholinv_la.h)
+                { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_prologue, dim3(nbatch, 1 + nt64), dim3(LA_THREADS), 0, stream, L, la, want_mode); }
+                for (int k = 0; k < nt64; k++) {
+                    const int nMF = std::max(nt64 - (k + 2), 0), nUF = (want_mode & 1) ? k + 1 : 0, nUL = (want_mode & 1) ? k : 0;
+                    const int nF = nMF + nUF + 1, nLrows = (k + 2 < nt64 && k >= 1) ? nMF + nUL + 1 : 0;
+                    Launcher l(c, KID_LA_STEP, stream);
+                    hipLaunchKernelGGL(k_la_step, dim3(nbatch, 1 + nF + nLrows * la.maxslice), dim3(LA_THREADS), 0, stream, L, la, k, want_mode);
+                }
+                { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_finish, dim3(nbatch, nt64), dim3(256), 0, stream, L, la, want_mode); }
             }
-            hipLaunchKernelGGL(k_ci_finish, dim3(nbatch), dim3(256), 0, stream, L);
             HIPCHK(c, hipMemcpyAsync(hst.data(), L.status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, stream));
             HIPCHK(c, hipStreamSynchronize(stream));
-            if (attempt < c->dbg_fail)   // test hook: this attempt counts as failed for every live problem
-                for (int bb = 0; bb < nbatch; bb++) if (hst[bb] >= 0) hst[bb] = -2;
+            if (attempt < c->dbg_fail)   // test hook: this attempt counts as failed for every live problem of this schedule
+                for (int bb = 0; bb < nbatch; bb++) if (hst[bb] >= 0 && (c->mc_old || big[bb])) hst[bb] = -2;
             bool retry = false, rewrite = false;
             for (int bb = 0; bb < nbatch; bb++) {
                 if (hst[bb] == -2) {
@@ -258,8 +318,8 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         // more patients than CUs: 4-wave workgroups, two per CU (the serial diagonal phase of one overlaps the
         // MFMA phase of the other); else 8 waves for the lowest latency per patient
         const int shape = c->cholinv_nw ? c->cholinv_nw : (nbatch > c->num_cu ? 44 : 84);
-        if (shape == 44) hipLaunchKernelGGL((k_cholinv<4, 4>), dim3(nbatch), dim3(256), 0, stream, L, want_mode);
-        else hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, want_mode);
+        if (shape == 44) hipLaunchKernelGGL((k_cholinv<4, 4>), dim3(nbatch), dim3(256), 0, stream, L, want_mode, 0);
+        else hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, want_mode, 0);
     }
     int from_slab = 0;
 #ifdef MEDGP_STAMPS
@@ -318,8 +378,10 @@ MedgpDev shifted_view(const MedgpDev &L, int b0) {
 int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, int flag_grad, bool need_inverse, int min_n,
                  double *nlml_dev, double *grad_dev, int32_t *status_dev, bool store_ukk = false) {
     c->last_has_inverse = flag_grad || need_inverse;
+    std::vector<int> ens(nbatch);   // n of every entry (host mirror)
+    for (int bb = 0; bb < nbatch; bb++) { const int es = c->h_bslot[bb]; ens[bb] = c->h_n[es >= c->max_slots ? es - c->max_slots : es]; }
     const bool split = !c->use_v0 && c->nsplit >= 2 && nbatch >= 2 * c->num_cu && c->aux[0] && c->aux[1];
-    if (!split) return run_pipeline_one(c, c->stream, c->dev, nbatch, max_n, theta_dev, flag_grad, need_inverse, min_n, nlml_dev, grad_dev, status_dev, store_ukk);
+    if (!split) return run_pipeline_one(c, c->stream, c->dev, nbatch, max_n, theta_dev, flag_grad, need_inverse, min_n, nlml_dev, grad_dev, status_dev, store_ukk, ens.data());
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     const int h = (nbatch / 2 + 1) & ~1;   // even: keeps the (b & 1) wave mirroring of k_cholinv consistent
     const int b0[2] = {0, h}, nb[2] = {h, nbatch - h};
@@ -328,7 +390,7 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
         MedgpDev V = shifted_view(c->dev, b0[i]);
         int rc = run_pipeline_one(c, c->aux[i], V, nb[i], max_n, theta_dev + (size_t)b0[i] * c->H, flag_grad, need_inverse, min_n,
                                   nlml_dev ? nlml_dev + b0[i] : nullptr, grad_dev ? grad_dev + (size_t)b0[i] * c->H : nullptr,
-                                  status_dev ? status_dev + b0[i] : nullptr, store_ukk);
+                                  status_dev ? status_dev + b0[i] : nullptr, store_ukk, ens.data() + b0[i]);
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(c->ev_join[i], c->aux[i]));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
@@ -377,6 +439,7 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     { const char *e = getenv("MEDGP_MULTI_CU"); c->force_mc = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_STREAMS"); c->nsplit = e ? atoi(e) : 1; }
     { const char *e = getenv("MEDGP_DEBUG_FAIL_ATTEMPTS"); c->dbg_fail = e ? atoi(e) : 0; }
+    { const char *e = getenv("MEDGP_MC_OLD"); c->mc_old = e ? atoi(e) : 0; }
     for (int i = 0; i < 2; i++) {
         (void)hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
         (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
@@ -723,7 +786,7 @@ int medgp_get_factor(medgp_ctx *c, int b, float *alpha, float *linv, float *beta
         V.bslot = c->d_one_slot;
         const bool prof = c->profiling;
         c->profiling = false;   // not part of the evaluation being measured
-        int rc = run_pipeline_one(c, c->stream, V, 1, n, nullptr, 0, true, 1, nullptr, nullptr, nullptr);
+        int rc = run_pipeline_one(c, c->stream, V, 1, n, nullptr, 0, true, 1, nullptr, nullptr, nullptr, false, &n);
         c->profiling = prof;
         if (rc) return rc;
         HIPCHK(c, hipMemcpyAsync(c->d_bslot + b, c->d_one_slot, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
