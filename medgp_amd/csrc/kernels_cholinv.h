@@ -26,6 +26,10 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // count on lgkmcnt, i.e. every LDS wait then waits for the HBM operands too).
 typedef __attribute__((address_space(1))) double gd_t;
 typedef __attribute__((address_space(1))) v2d gv2d_t;
+// LDS views for the helpers that receive tile pointers (an out-of-line callee otherwise falls back to FLAT accesses)
+typedef __attribute__((address_space(3))) double ld_t;
+typedef __attribute__((address_space(3))) v2d lv2d_t;
+typedef __attribute__((address_space(3))) int li_t;
 
 #ifndef CI_KC
 #define CI_KC 16          // k-columns staged per barrier; the history operand is loaded 16 columns at a time
@@ -64,7 +68,7 @@ struct CholInvSmem {
     };
     double Xk[64][66];             // L_kk^-1 (lower, exact zeros above the diagonal)
     double zacc[64];               // L[C_k, 0:64k] z[0:64k]
-    double rhs[64];
+    alignas(16) double rhs[64 + 128];          // diag(L_kk) during the factor (+ 128 doubles of diag16 scratch), then the z right-hand side
     double zk[64];                 // z of the current panel (for the in-step alpha accumulation)
     double zs[1024];               // z history kept in LDS for n <= 1024: the in-loop z product then issues no
                                    // global loads, whose wait (vmcnt) would also drain the operand loads
@@ -86,7 +90,7 @@ __device__ inline double readlane_d(double v, int srclane) {   // srclane must b
 // 16x16 tile product on one wave, operands in LDS (row stride CI_S): returns c + op(A) op(B),
 // op(A)[i][k] = TA ? A[k][i] : A[i][k], op(B)[k][j] = TB ? B[j][k] : B[k][j].
 template <bool TA, bool TB>
-__device__ inline v4d tile_mm(const double *Ap, const double *Bp, v4d c, int li, int g) {
+__device__ inline v4d tile_mm(const ld_t *Ap, const ld_t *Bp, v4d c, int li, int g) {
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         double a = TA ? Ap[(4 * s + g) * CI_S + li] : Ap[li * CI_S + 4 * s + g];
@@ -95,13 +99,13 @@ __device__ inline v4d tile_mm(const double *Ap, const double *Bp, v4d c, int li,
     }
     return c;
 }
-__device__ inline v4d tile_ld(const double *Cp, int li, int g) {
+__device__ inline v4d tile_ld(const ld_t *Cp, int li, int g) {
     v4d c;
 #pragma unroll
     for (int r = 0; r < 4; r++) c[r] = Cp[(4 * r + g) * CI_S + li];
     return c;
 }
-__device__ inline void tile_st(double *Cp, v4d c, int li, int g) {
+__device__ inline void tile_st(ld_t *Cp, v4d c, int li, int g) {
 #pragma unroll
     for (int r = 0; r < 4; r++) Cp[(4 * r + g) * CI_S + li] = c[r];
 }
@@ -114,7 +118,13 @@ __device__ inline void tile_st(double *Cp, v4d c, int li, int g) {
 // zeros above the diagonal); dv[0..16) receives diag(L).  Returns false on a bad pivot (LAPACK potf2 rule: pivot <= 0
 // or NaN); there is no early exit -- the 16 steps are ONE basic block, so the column updates of step j overlap the
 // reciprocal-square-root chain of step j + 1 (a bad pivot just propagates NaNs that nobody uses).
-__device__ inline bool diag16(double *T, double *X, double *dv, int lane) {
+// Instruction count is what bounds it (one wave alone issues a 64-bit VALU instruction every ~8 cycles; 8.0 k cycles per
+// tile with all 15 + 14 + ... trailing updates fed by v_readlane pairs).  The columns are therefore taken four at a time:
+// inside a 4-column panel the (critical-path) updates use v_readlane, the rows of the finished panel are then published to
+// a 512-byte LDS scratch and the updates of the columns right of the panel read their four multipliers as broadcast
+// ds_read_b128 pairs -- 60 LDS reads instead of 240 v_readlane per tile.  Every a[c] still receives the same FMAs in the
+// same (ascending j) order: results are bit-identical to the all-readlane form.  scr: 128 doubles of LDS owned by this wave.
+__device__ __forceinline__ bool diag16(ld_t *T, ld_t *X, ld_t *dv, ld_t *scr, int lane) {
     const int i = lane & 15, i5 = lane & 31;
     const bool ident = i5 >= 16;
     double a[16];
@@ -126,24 +136,44 @@ __device__ inline bool diag16(double *T, double *X, double *dv, int lane) {
     bool ok = true;
     double dj = 1.0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const double piv = readlane_d(a[j], j);
-        ok = ok && (piv > 0.0);
-        // sqrt and reciprocal sqrt together: v_rsq_f64 seed + two coupled Goldschmidt steps + one residual
-        // correction (about 1 ulp each; pivots of a scaled covariance never need the denormal rescaling that makes
-        // the library sqrt + divide a ~450-cycle dependent chain on this serial path)
-        const double y0 = __builtin_amdgcn_rsq(piv);
-        double gg = piv * y0, hh = 0.5 * y0;
-        double rr = fma(-gg, hh, 0.5);
-        gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
-        rr = fma(-gg, hh, 0.5);
-        gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
-        const double dd = fma(-gg, gg, piv);
-        const double sq = fma(dd, hh, gg), rinv = hh + hh;
-        dj = (i5 == j) ? sq : dj;
-        a[j] = (i5 == j) ? sq : a[j] * rinv;
+    for (int p = 0; p < 4; p++) {
 #pragma unroll
-        for (int c = j + 1; c < 16; c++) a[c] -= a[j] * readlane_d(a[j], c);
+        for (int k = 0; k < 4; k++) {
+            const int j = 4 * p + k;
+            const double piv = readlane_d(a[j], j);
+            ok = ok && (piv > 0.0);
+            // sqrt and reciprocal sqrt together: v_rsq_f64 seed + two coupled Goldschmidt steps + one residual
+            // correction (about 1 ulp each; pivots of a scaled covariance never need the denormal rescaling that makes
+            // the library sqrt + divide a ~450-cycle dependent chain on this serial path)
+            const double y0 = __builtin_amdgcn_rsq(piv);
+            double gg = piv * y0, hh = 0.5 * y0;
+            double rr = fma(-gg, hh, 0.5);
+            gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
+            rr = fma(-gg, hh, 0.5);
+            gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
+            const double dd = fma(-gg, gg, piv);
+            const double sq = fma(dd, hh, gg), rinv = hh + hh;
+            dj = (i5 == j) ? sq : dj;
+            a[j] = (i5 == j) ? sq : a[j] * rinv;
+#pragma unroll
+            for (int k2 = k + 1; k2 < 4; k2++) a[4 * p + k2] -= a[j] * readlane_d(a[j], 4 * p + k2);
+        }
+        if (p < 3) {
+            ld_t *sp = scr + 64 * (p & 1);
+            if (lane < 16) {
+                *(lv2d_t *)&sp[4 * lane] = (v2d){a[4 * p], a[4 * p + 1]};
+                *(lv2d_t *)&sp[4 * lane + 2] = (v2d){a[4 * p + 2], a[4 * p + 3]};
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 4 * p + 4; c < 16; c++) {
+                const v2d l01 = *(const lv2d_t *)&sp[4 * c], l23 = *(const lv2d_t *)&sp[4 * c + 2];
+                a[c] -= a[4 * p] * l01[0];
+                a[c] -= a[4 * p + 1] * l01[1];
+                a[c] -= a[4 * p + 2] * l23[0];
+                a[c] -= a[4 * p + 3] * l23[1];
+            }
+        }
     }
     if (lane < 16) {
         dv[lane] = dj;
@@ -172,7 +202,7 @@ __device__ unsigned long long g_diag_dbg[8];
 // computed TRANSPOSED (lt = X(t,t) D(s,t)^T = L(s,t)^T): lt is at once the A operand L(s,t) and the B operand L(u,t)^T of
 // the trailing update, and the partial sums P of the inverse feed X(s,s) P straight from their accumulators -- no LDS
 // round trips between dependent products, and all LDS reads of a stage are issued before its MFMAs.
-__device__ __forceinline__ void diag_factor_wave_body(double *D, double *X, double *dv, int *fail, double *logdet, int lane) {
+__device__ __forceinline__ void diag_factor_wave_body(ld_t *D, ld_t *X, ld_t *dv, li_t *fail, ld_t *logdet, int lane) {
     const int li = lane & 15, g = lane >> 4;
 #define TD(s, t) (D + (16 * (s)) * CI_S + 16 * (t))
 #define TX(s, t) (X + (16 * (s)) * CI_S + 16 * (t))
@@ -183,7 +213,7 @@ __device__ __forceinline__ void diag_factor_wave_body(double *D, double *X, doub
 #endif
 #pragma unroll 1
     for (int t = 0; t < 4; t++) {
-        if (!diag16(TD(t, t), TX(t, t), dv + 16 * t, lane)) { if (lane == 0) *fail = 1; return; }
+        if (!diag16(TD(t, t), TX(t, t), dv + 16 * t, dv + 64, lane)) { if (lane == 0) *fail = 1; return; }
         __builtin_amdgcn_wave_barrier();
         DSTAMP(0);
         if (t == 3) break;
@@ -289,7 +319,7 @@ __device__ __forceinline__ void diag_factor_wave_body(double *D, double *X, doub
 // Out of line: bounds the register pressure around the call.  (A 16-wave shape -- 8 waves x 2 units, 128 VGPRs, four waves
 // per SIMD -- was measured at 2.78 ms against 1.66 ms for 4 waves x 4 units at 512 x N=512: the callee does not inherit a
 // smaller register budget, and inlined into 128 VGPRs the kernel spills in every phase.)
-__device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X, double *dv, int *fail, double *logdet, int lane) {
+__device__ __attribute__((noinline)) void diag_factor_wave(ld_t *D, ld_t *X, ld_t *dv, li_t *fail, ld_t *logdet, int lane) {
     diag_factor_wave_body(D, X, dv, fail, logdet, lane);
 }
 
@@ -302,7 +332,7 @@ __device__ __attribute__((noinline)) void diag_factor_wave(double *D, double *X,
 //               X(t, 0..t-1) = -X(t,t) sum_u L(t,u) X(u,.)  (needs only diagonal inverses <= t)       | barrier
 //   tail      : X(3, 0..2) on three waves, zero tiles, log det.
 // Critical path: 4 diag16 + 3 (panel + one trailing tile + 2 barriers) + one inverse row.
-__device__ __forceinline__ void inv_row_tiles(double *D, double *X, int s2, int t, int li, int g) {
+__device__ __forceinline__ void inv_row_tiles(ld_t *D, ld_t *X, int s2, int t, int li, int g) {
     // X(s2,t) = -X(s2,s2) P,  P = sum_{u=t}^{s2-1} L(s2,u) X(u,t)
 #define TD(s, t) (D + (16 * (s)) * CI_S + 16 * (t))
 #define TX(s, t) (X + (16 * (s)) * CI_S + 16 * (t))
@@ -313,18 +343,18 @@ __device__ __forceinline__ void inv_row_tiles(double *D, double *X, int s2, int 
     for (int r = 0; r < 4; r++) xo = __builtin_amdgcn_mfma_f64_16x16x4f64(-TX(s2, s2)[li * CI_S + 4 * r + g], pp[r], xo, 0, 0, 0);
     tile_st(TX(s2, t), xo, li, g);
 }
-__device__ __forceinline__ void trail_tile(double *D, int s2, int u, int t, int li, int g) {
+__device__ __forceinline__ void trail_tile(ld_t *D, int s2, int u, int t, int li, int g) {
     v4d c = tile_ld(TD(s2, u), li, g);
 #pragma unroll
     for (int k = 0; k < 4; k++)
         c = __builtin_amdgcn_mfma_f64_16x16x4f64(-TD(s2, t)[li * CI_S + 4 * k + g], TD(u, t)[li * CI_S + 4 * k + g], c, 0, 0, 0);
     tile_st(TD(s2, u), c, li, g);
 }
-__device__ __attribute__((noinline)) void diag_factor_wg(double *D, double *X, double *dv, int *fail, double *logdet, int wave, int lane) {
+__device__ __attribute__((noinline)) void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t *fail, ld_t *logdet, int wave, int lane) {
     const int li = lane & 15, g = lane >> 4;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
     if (wave == 0) {
-        if (!diag16(TD(0, 0), TX(0, 0), dv, lane)) { if (lane == 0) *fail = 1; }
+        if (!diag16(TD(0, 0), TX(0, 0), dv, dv + 64, lane)) { if (lane == 0) *fail = 1; }
     }
     __syncthreads();
     if (*fail) return;
@@ -341,7 +371,7 @@ __device__ __attribute__((noinline)) void diag_factor_wg(double *D, double *X, d
         if (wave == 0) {
             trail_tile(D, t + 1, t + 1, t, li, g);
             __builtin_amdgcn_wave_barrier();
-            if (!diag16(TD(t + 1, t + 1), TX(t + 1, t + 1), dv + 16 * (t + 1), lane)) { if (lane == 0) *fail = 1; }
+            if (!diag16(TD(t + 1, t + 1), TX(t + 1, t + 1), dv + 16 * (t + 1), dv + 64, lane)) { if (lane == 0) *fail = 1; }
         } else if (wave < 4) {
             // remaining trailing tiles (s,u), t+1 <= u <= s <= 3, (s,u) != (t+1,t+1): dealt round-robin to waves 1..3
             int e = 0;
@@ -608,9 +638,9 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 __syncthreads();
                 STAMP(0);   // wait for the slowest GEMM wave (folded into 0)
 #ifdef CI_DIAG_ONE_WAVE
-                if (wave == 0) diag_factor_wave(&sm.Dk[0][0], &sm.Xk[0][0], sm.rhs, &sm.fail, &sm.logdet, lane);
+                if (wave == 0) diag_factor_wave((ld_t *)&sm.Dk[0][0], (ld_t *)&sm.Xk[0][0], (ld_t *)sm.rhs, (li_t *)&sm.fail, (ld_t *)&sm.logdet, lane);
 #else
-                diag_factor_wg(&sm.Dk[0][0], &sm.Xk[0][0], sm.rhs, &sm.fail, &sm.logdet, wave, lane);
+                diag_factor_wg((ld_t *)&sm.Dk[0][0], (ld_t *)&sm.Xk[0][0], (ld_t *)sm.rhs, (li_t *)&sm.fail, (ld_t *)&sm.logdet, wave, lane);
 #endif
                 if (wave == 0) {
                     STAMP(3);   // diagonal factor

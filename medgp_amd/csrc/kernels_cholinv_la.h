@@ -52,7 +52,7 @@ struct LaSmem {
         double Xs[64][LA_S];             // X_k (trsm), later D_k+1 (factor input)
     };
     double Ls[64][LA_S];                 // L[C_k+1, C_k] (B operand of the newest rank-64 term), later X_k+1 (factor output)
-    double dv[64];
+    alignas(16) double dv[64 + 128];                 // diag(L_kk) + the panel scratch of diag16
     double logdet;
     int fail;
 };
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
     if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
     for (int e = tid; e < 64 * 64; e += LA_THREADS) { const int rr = e >> 6, cc = e & 63; sm.Xs[rr][cc] = (cc <= rr) ? Lb[(size_t)rr * ld + cc] : 0.0; }
     __syncthreads();
-    diag_factor_wg(&sm.Xs[0][0], &sm.Ls[0][0], sm.dv, &sm.fail, &sm.logdet, w, lane);
+    diag_factor_wg((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.Ls[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, w, lane);
     __syncthreads();
     if (sm.fail) { if (tid == 0) L.status[b] = -2; return; }
     double *Xg = A.xk2 + ((size_t)b * 2 + 0) * 4096;
@@ -260,6 +260,16 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     const double *Xg = A.xk2 + ((size_t)b * 2 + (k & 1)) * 4096;
     const bool is_D = (role == 0);
     if (is_D && !has_next) return;                // the last panel has no next diagonal block
+    // ---- (0) every global operand of this role is requested up front (X_k, the pre-solve copy P_k+1,k, the role's own block
+    //      of panel k, the initial block of panel k+1): one memory round trip instead of four dependent ones on the
+    //      critical path of the step; the history product below hides it
+    v2d xreg[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) xreg[e] = *(const v2d *)(Xg + 2 * (tid + LA_THREADS * e));
+    v4d pval[4], oval[4];
+    if (has_next) la_load_t(A.pnx + ((size_t)b * 2 + (k & 1)) * 4096 + (size_t)(16 * w) * 64, 64, pval, li, g);
+    double *oblk = Rb + (size_t)(16 * w) * ld + c0;
+    if (!is_D) la_load_t(oblk, ld, oval, li, g);
     // ---- (1) pre-solve block of panel k+1: acc = -init + partials + term of panel k-1     (non-transposed tiles)
     v4d acc[4];
 #pragma unroll
@@ -285,14 +295,13 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
         if (k >= 1 && jf <= k - 1) la_gemm(Rb, Lb + (size_t)c1 * ld, ld, k - 1, k, acc, sm, tid, w, li, g);
     }
     // ---- (2) X_k -> LDS (Bs is dead: la_gemm ends with a barrier)
-    for (int e = tid; e < 64 * 64; e += LA_THREADS) sm.Xs[e >> 6][e & 63] = Xg[e];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { const int idx = 2 * (tid + LA_THREADS * e); *(v2d *)&sm.Xs[idx >> 6][idx & 63] = xreg[e]; }
     __syncthreads();
     // ---- (3) L[C_k+1, C_k] = P_k+1,k X_k^T for the wave's 16 rows of block k+1 -> LDS (and, D only, to memory)
     v4d o[4];
     if (has_next) {
-        v4d val[4];
-        la_load_t(A.pnx + ((size_t)b * 2 + (k & 1)) * 4096 + (size_t)(16 * w) * 64, 64, val, li, g);
-        la_trsm(sm.Xs, val, o, li, g);
+        la_trsm(sm.Xs, pval, o, li, g);
 #pragma unroll
         for (int ct = 0; ct < 4; ct++)
 #pragma unroll
@@ -302,13 +311,12 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     // ---- (4) own rows of panel k: row_r[C_k] = P_r,k X_k^T   (D: that is the block above, already in o;  U_k: the
     //      diagonal block U_kk itself, final since the previous launch)
     if (!is_D) {
-        double *blk = Rb + (size_t)(16 * w) * ld + c0;
-        if (row.kind == 1 && row.blk == k) la_load_t(blk, ld, o, li, g);
-        else {
-            v4d val[4];
-            la_load_t(blk, ld, val, li, g);
-            la_trsm(sm.Xs, val, o, li, g);
-            la_store_t(blk, ld, o, li, g);
+        if (row.kind == 1 && row.blk == k) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++) o[ct] = oval[ct];
+        } else {
+            la_trsm(sm.Xs, oval, o, li, g);
+            la_store_t(oblk, ld, o, li, g);
         }
     }
     if (!has_next) return;
@@ -346,7 +354,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
 #pragma unroll
         for (int r = 0; r < 4; r++) sm.Xs[16 * w + 4 * r + g][16 * ct + li] = -acc[ct][r];
     __syncthreads();
-    diag_factor_wg(&sm.Xs[0][0], &sm.Ls[0][0], sm.dv, &sm.fail, &sm.logdet, w, lane);
+    diag_factor_wg((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.Ls[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, w, lane);
     __syncthreads();
     if (sm.fail) { if (tid == 0) L.status[b] = -2; return; }
     double *Xn = A.xk2 + ((size_t)b * 2 + ((k + 1) & 1)) * 4096;
@@ -360,30 +368,37 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
 }
 
 // ---- epilogue of the factorisation: z, quad = z^T z, alpha = U z, status = jitter count -----------------------------------
-// grid = (nbatch, nbmax): block y owns rows 64 y .. of alpha; block 0 also publishes quad and the status
+// grid = (nbatch, 4 nbmax): block y owns rows 16 y .. 16 y + 15 of alpha (16 lanes per row, four independent loads in flight
+// per lane); block 0 also publishes quad and the status
 __global__ void __launch_bounds__(256) k_la_finish(MedgpDev L, LaArgs A, int want_mode) {
     __shared__ double red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (L.status[b] < 0) return;
     const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
-    const int rb = blockIdx.y;
-    if (rb >= nb || nb < 2) return;
+    const int rq = blockIdx.y;
+    if (16 * rq >= npad || nb < 2) return;
     const double *zrow = A.ybuf + (size_t)b * 64 * ld;   // row 0 of the Y block
+    const int i = 16 * rq + 4 * w + (lane >> 4), li = lane & 15;
     if (want_mode & 1) {
-        const double *U = L.Linv + (size_t)b * ld * ld;
-        for (int r = w; r < 64; r += 4) {       // alpha_i = sum_{c >= 64 rb} U[i][c] z[c]  (zeros left of the diagonal inside the block)
-            const int i = 64 * rb + r;
-            const double *ur = U + (size_t)i * ld;
-            double s = 0.0;
-            for (int c = 64 * rb + lane; c < npad; c += 64) s += ur[c] * zrow[c];
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-            if (lane == 0) L.alpha[(size_t)b * ld + i] = s;
+        // alpha_i = sum_{c >= 64 (i / 64)} U[i][c] z[c]   (U has exact zeros left of the diagonal inside its diagonal block)
+        const double *ur = L.Linv + (size_t)b * ld * ld + (size_t)i * ld;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int c = (i & ~63) + li;
+        for (; c + 48 < npad; c += 64) {
+            s0 += ur[c] * zrow[c];
+            s1 += ur[c + 16] * zrow[c + 16];
+            s2 += ur[c + 32] * zrow[c + 32];
+            s3 += ur[c + 48] * zrow[c + 48];
         }
+        for (; c < npad; c += 16) s0 += ur[c] * zrow[c];
+        double s = (s0 + s1) + (s2 + s3);
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (li == 0) L.alpha[(size_t)b * ld + i] = s;
     }
-    for (int c = 64 * rb + tid; c < 64 * rb + 64; c += 256) L.z[(size_t)b * ld + c] = zrow[c];
-    if (rb == 0) {
+    if (tid < 16) L.z[(size_t)b * ld + 16 * rq + tid] = zrow[16 * rq + tid];
+    if (rq == 0) {
         double s = 0.0;
-        for (int i = tid; i < npad; i += 256) s += zrow[i] * zrow[i];
+        for (int k2 = tid; k2 < npad; k2 += 256) s += zrow[k2] * zrow[k2];
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
         if (lane == 0) red[w] = s;
         __syncthreads();

@@ -20,7 +20,9 @@ struct McSmem {
         double Dk[64][66];
     };
     double Xk[64][66];
-    double zacc[64], rhs[64], zk[64], rdiag[16];
+    double zacc[64];
+    alignas(16) double rhs[64 + 128];
+    double zk[64], rdiag[16];
     double logdet;
     int fail;
 };
@@ -30,7 +32,7 @@ static_assert(sizeof(double) * 2 * 64 * (MC_KC + 2) >= sizeof(double) * 64 * 66,
 __device__ inline void mc_diag_factor(McSmem &sm, int lane) {
     if (lane == 0) sm.logdet = 0.0;
     __builtin_amdgcn_wave_barrier();
-    diag_factor_wave(&sm.Dk[0][0], &sm.Xk[0][0], sm.rhs, &sm.fail, &sm.logdet, lane);
+    diag_factor_wave((ld_t *)&sm.Dk[0][0], (ld_t *)&sm.Xk[0][0], (ld_t *)sm.rhs, (li_t *)&sm.fail, (ld_t *)&sm.logdet, lane);
 }
 
 // grid = (nbatch, max blocks), block = 256 (4 waves x 16 rows)

@@ -11,6 +11,15 @@
 // The tables implement cos(w (t_i - t_j)) = cs_i cs_j + sn_i sn_j, so the N^2 pair loop needs no
 // trigonometric evaluation (c_kernel_LMC_SM.cpp:374-378 evaluates cos per pair).
 // ------------------------------------------------------------------------------------------
+// grid = (nbatch, 1 + table chunks): block y = 0 transforms the hypers (and resets the per-entry state), blocks y >= 1 fill
+// PREP_CHUNK entries of the cos / sin tables each (they derive w_q from theta themselves, so no block waits for another;
+// one workgroup per entry made a single N = 4096, Q = 5 evaluation spend 0.12 ms here).
+#define PREP_CHUNK 2048
+__device__ __forceinline__ double prep_w(const MedgpDev &L, const double *th, int q) {
+    if (L.kidx == 7) return 2.0 * L.pi * exp(th[L.D + L.Q * L.D * L.R + q]);
+    if (L.kidx == 8) return 2.0 * L.pi * exp(th[1 + L.Q + q]);
+    return 0.0;
+}
 __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restrict__ theta, int min_n) {
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int slot = L.bslot[b];
@@ -20,6 +29,24 @@ __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restri
     double *sig2 = hyp, *B = hyp + hyp_off_B(L), *w = hyp + hyp_off_w(L), *c = hyp + hyp_off_c(L);
     const int Q = L.Q, D = L.D, R = L.R;
     const double pi = L.pi;
+    if (blockIdx.y >= 1) {
+        // ---- cos / sin tables.  theta == nullptr (tables only, medgp_get_factor's caller-order re-factorisation): the
+        //      hyper block of this entry is kept, w_q is read from it
+        const double *t = L.pt + (size_t)slot * L.ldn;
+        double *cs = L.cs + (size_t)b * Q * L.ldn, *sn = L.sn + (size_t)b * Q * L.ldn;
+        const int lo = (blockIdx.y - 1) * PREP_CHUNK, hi = min(lo + PREP_CHUNK, Q * L.ldn);
+        for (int idx = lo + tid; idx < hi; idx += nt) {
+            const int q = idx / L.ldn, i = idx - q * L.ldn;
+            double s = 0.0, co = 0.0;
+            if (i < n) {
+                const double wq = theta ? prep_w(L, th, q) : w[q];
+                sincos(wq * t[i], &s, &co);
+            }
+            cs[idx] = co;
+            sn[idx] = s;
+        }
+        return;
+    }
     if (tid == 0) {
         // objective path: n > 2 (ref util/c_objective_one.cpp:51); train(false)+predict path: any n >= 1
         // (GP_Regression::train has no such guard, ref core/gp_regression.cpp:102-126)
@@ -28,10 +55,8 @@ __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restri
         L.scal[b * 4 + 1] = 0.0;
         L.jit[b] = 0;
     }
-    if (theta == nullptr) {
-        // tables only: the hyper block of this entry is kept (medgp_get_factor re-factors an entry in the caller's
-        // observation order; sigma^2, B_q, w_q, c_q do not depend on the order, the cos / sin tables do)
-    } else if (L.kidx == 7) {
+    if (theta == nullptr) return;
+    if (L.kidx == 7) {
         for (int d = tid; d < D; d += nt) { double s = exp(th[d]); sig2[d] = s * s; }
         const double *A = th + D, *lk = th + D + Q * (D * R + 2);
         for (int idx = tid; idx < Q * D * D; idx += nt) {
@@ -43,18 +68,18 @@ __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restri
             B[idx] = s;
         }
         for (int q = tid; q < Q; q += nt) {
-            double mu = exp(th[D + Q * D * R + q]), v = exp(th[D + Q * D * R + Q + q]);
+            double v = exp(th[D + Q * D * R + Q + q]);
             double pv = pi * v;
-            w[q] = 2.0 * pi * mu;
+            w[q] = prep_w(L, th, q);
             c[q] = 2.0 * (pv * pv);
         }
     } else if (L.kidx == 8) {  // SM: theta = [log sigma | log w | log mu | log v]
         if (tid == 0) { double s = exp(th[0]); sig2[0] = s * s; }
         for (int q = tid; q < Q; q += nt) {
             B[q] = exp(th[1 + q]);
-            double mu = exp(th[1 + Q + q]), v = exp(th[1 + 2 * Q + q]);
+            double v = exp(th[1 + 2 * Q + q]);
             double pv = pi * v;
-            w[q] = 2.0 * pi * mu;
+            w[q] = prep_w(L, th, q);
             c[q] = 2.0 * (pv * pv);
         }
     } else {  // SE: theta = [log sigma | log l | log sf];  k = sf^2 exp(-d^2 / (2 l^2))
@@ -65,16 +90,6 @@ __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restri
             w[0] = 0.0;
             c[0] = 0.5 / (l * l);
         }
-    }
-    __syncthreads();
-    const double *t = L.pt + (size_t)slot * L.ldn;
-    double *cs = L.cs + (size_t)b * Q * L.ldn, *sn = L.sn + (size_t)b * Q * L.ldn;
-    for (int idx = tid; idx < Q * L.ldn; idx += nt) {
-        int q = idx / L.ldn, i = idx - q * L.ldn;
-        double s = 0.0, co = 0.0;
-        if (i < n) sincos(w[q] * t[i], &s, &co);
-        cs[idx] = co;
-        sn[idx] = s;
     }
 }
 
@@ -450,6 +465,45 @@ __global__ void __launch_bounds__(256) k_gradbins_v0(MedgpDev L) {
 //   ref: c_inference_exact.cpp:146-152 (nlml), :177-219 (order), c_inference_prior.cpp:60-150,
 //        prior/c_prior.cpp:383-421
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// stage 5b: block sums S, SM, SV from the pieces k_wgrad left in the slab, added in a FIXED order (row pieces outer, column
+// pieces inner): bitwise reproducible.  grid = (nbatch, ceil(3 Q D(D+1)/2 / 256)), one bin per thread (inside k_epilogue a
+// single workgroup per entry walked all bins: 0.44 ms for one D = 64, N = 4096 evaluation).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_slabsum(MedgpDev L) {
+    __shared__ int s_roff[MEDGP_MAX_D + 1], s_coff[MEDGP_MAX_D + 1], s_seg[MEDGP_MAX_D + 1];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (L.status[b] < 0) return;
+    const int Q = L.Q, D = L.D;
+    const int slot = L.bslot[b];
+    for (int i = tid; i <= D; i += nt) {
+        s_roff[i] = L.proff[(size_t)slot * (D + 1) + i];
+        s_coff[i] = L.pcoff[(size_t)slot * (D + 1) + i];
+        s_seg[i] = L.pseg[(size_t)slot * (D + 1) + i];
+    }
+    __syncthreads();
+    const int *roff = s_roff, *coff = s_coff, *seg = s_seg;
+    const double *slab = L.slab + (size_t)b * L.slab_stride;
+    const int nbins = D * (D + 1) / 2;
+    const int idx = blockIdx.y * nt + tid;
+    if (idx >= 3 * Q * nbins) return;
+    const int pq = idx / nbins;          // plane * Q + q
+    int d, e;
+    tile_decode(idx - pq * nbins, d, e);
+    const double *sl = slab + (size_t)pq * L.slab_R * L.slab_C;
+    double s = 0.0;
+    for (int rs = roff[d]; rs < roff[d + 1]; rs++) {
+        const int It = (seg[d] / 16 + (rs - roff[d])) / 4;
+        for (int cs = coff[e]; cs < coff[e + 1]; cs++) {
+            const int Jt = seg[e] / 64 + (cs - coff[e]);
+            if (Jt <= It) s += sl[(size_t)rs * L.slab_C + cs];
+        }
+    }
+    const int pl = pq / Q, q = pq - pl * Q;
+    double *dst = (pl == 0 ? L.S : (pl == 1 ? L.SM : L.SV)) + (size_t)b * Q * D * D;
+    dst[(size_t)q * D * D + d * D + e] = s;
+}
+
 __device__ inline void prior_apply(const MedgpPrior &p, double hv, double pi, bool want_grad, double &lp_sum, double &g) {
     if (!p.flag) return;
     if (p.type == 0) { if (want_grad) g = 0.0; return; }
@@ -497,38 +551,6 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
     // diag(W): k_wgrad exports it; the v0 path keeps the full W in the Kmat buffer
     const double *Wd = from_slab ? L.wdiag + (size_t)b * ld : L.Kmat + (size_t)b * ld * ld;
     const size_t wds = from_slab ? 1 : (size_t)ld + 1;
-    if (flag_grad && from_slab) {
-        // add the pieces written by k_wgrad in a fixed order: rows pieces outer, column pieces inner
-        // offset tables -> LDS first: every bin below would otherwise start with a chain of dependent global loads
-        __shared__ int s_roff[MEDGP_MAX_D + 1], s_coff[MEDGP_MAX_D + 1], s_seg[MEDGP_MAX_D + 1];
-        for (int i = tid; i <= D; i += nt) {
-            s_roff[i] = L.proff[(size_t)slot * (D + 1) + i];
-            s_coff[i] = L.pcoff[(size_t)slot * (D + 1) + i];
-            s_seg[i] = L.pseg[(size_t)slot * (D + 1) + i];
-        }
-        __syncthreads();
-        const int *roff = s_roff, *coff = s_coff, *seg = s_seg;
-        const double *slab = L.slab + (size_t)b * L.slab_stride;
-        const int nbins = D * (D + 1) / 2;
-        for (int idx = tid; idx < 3 * Q * nbins; idx += nt) {
-            const int pq = idx / nbins;          // plane * Q + q
-            int d, e;
-            tile_decode(idx - pq * nbins, d, e);
-            const double *sl = slab + (size_t)pq * L.slab_R * L.slab_C;
-            double s = 0.0;
-            for (int rs = roff[d]; rs < roff[d + 1]; rs++) {
-                const int It = (seg[d] / 16 + (rs - roff[d])) / 4;
-                for (int cs = coff[e]; cs < coff[e + 1]; cs++) {
-                    const int Jt = seg[e] / 64 + (cs - coff[e]);
-                    if (Jt <= It) s += sl[(size_t)rs * L.slab_C + cs];
-                }
-            }
-            const int pl = pq / Q, q = pq - pl * Q;
-            double *dst = (pl == 0 ? L.S : (pl == 1 ? L.SM : L.SV)) + (size_t)b * Q * D * D;
-            dst[(size_t)q * D * D + d * D + e] = s;
-        }
-        __syncthreads();
-    }
     if (lds_sa) {
         for (int i = tid; i < Q * D * D; i += nt) s_S[i] = S[i];   // lower triangles are the ones sym_get reads
         for (int i = tid; i < Q * D * R; i += nt) s_A[i] = th[D + i];

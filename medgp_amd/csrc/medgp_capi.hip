@@ -226,7 +226,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
                      int flag_grad, bool need_inverse, int min_n, double *nlml_dev, double *grad_dev, int32_t *status_dev,
                      bool store_ukk, const int *entry_n) {
     const int nt64 = medgp_roundup(std::max(max_n, 1), 64) / 64;
-    { Launcher l(c, KID_PREP, stream); hipLaunchKernelGGL(k_prep, dim3(nbatch), dim3(256), 0, stream, L, theta_dev, min_n); }
+    { Launcher l(c, KID_PREP, stream); hipLaunchKernelGGL(k_prep, dim3(nbatch, 1 + (L.Q * L.ldn + PREP_CHUNK - 1) / PREP_CHUNK), dim3(256), 0, stream, L, theta_dev, min_n); }
     auto launch_assemble = [&]() {
         Launcher l(c, KID_ASSEMBLE, stream);
         const dim3 tg(tri(nt64), nbatch), tb(256);
@@ -287,7 +287,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
                     Launcher l(c, KID_LA_STEP, stream);
                     hipLaunchKernelGGL(k_la_step, dim3(nbatch, 1 + nF + nLrows * la.maxslice), dim3(LA_THREADS), 0, stream, L, la, k, want_mode);
                 }
-                { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_finish, dim3(nbatch, nt64), dim3(256), 0, stream, L, la, want_mode); }
+                { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_finish, dim3(nbatch, 4 * nt64), dim3(256), 0, stream, L, la, want_mode); }
             }
             HIPCHK(c, hipMemcpyAsync(hst.data(), L.status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, stream));
             HIPCHK(c, hipStreamSynchronize(stream));
@@ -347,6 +347,11 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
             const int nbins = L.Q * tri(L.D);
             { Launcher l(c, KID_GRADBINS, stream); hipLaunchKernelGGL(k_gradbins_v0, dim3((nbins + 255) / 256, nbatch), dim3(256), 0, stream, L); }
         }
+    }
+    if (flag_grad && from_slab) {
+        const int nbins3 = 3 * L.Q * tri(L.D);
+        Launcher l(c, KID_EPILOGUE, stream);
+        hipLaunchKernelGGL(k_slabsum, dim3(nbatch, (nbins3 + 255) / 256), dim3(256), 0, stream, L);
     }
     if (nlml_dev) {
         Launcher l(c, KID_EPILOGUE, stream);

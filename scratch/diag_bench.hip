@@ -6,7 +6,7 @@
 #include "../medgp_amd/csrc/medgp_dev.h"
 __device__ __attribute__((noinline)) void reassemble_wg(const MedgpDev &, int, int, int, int, int) {}
 #include "../medgp_amd/csrc/kernels_cholinv.h"
-struct Sm { double D[64][66], X[64][66], dv[64], logdet; int fail; };
+struct Sm { double D[64][66], X[64][66]; alignas(16) double dv[64 + 128]; double logdet; int fail; };
 template <int MODE>
 __global__ void __launch_bounds__(256) k(const double *A, double *outL, double *outX, unsigned long long *cyc, int reps) {
     __shared__ Sm sm;
@@ -17,8 +17,8 @@ __global__ void __launch_bounds__(256) k(const double *A, double *outL, double *
         if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
         __syncthreads();
         unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        if (MODE == 0) { if (wave == 0) diag_factor_wave(&sm.D[0][0], &sm.X[0][0], sm.dv, &sm.fail, &sm.logdet, lane); __syncthreads(); }
-        else diag_factor_wg(&sm.D[0][0], &sm.X[0][0], sm.dv, &sm.fail, &sm.logdet, wave, lane);
+        if (MODE == 0) { if (wave == 0) diag_factor_wave((ld_t *)&sm.D[0][0], (ld_t *)&sm.X[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, lane); __syncthreads(); }
+        else diag_factor_wg((ld_t *)&sm.D[0][0], (ld_t *)&sm.X[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, wave, lane);
         unsigned long long t1 = __builtin_amdgcn_s_memtime();
         tot += t1 - t0;
         __syncthreads();
