@@ -522,7 +522,10 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 isM[u] = bidx < nM;
                 const int rblk = isM[u] ? (k + bidx) : (bidx - nM);
                 rowb[u] = 64 * rblk + 16 * wu;
-                cf[u] = act[u] ? (isM[u] ? 0 : (64 * rblk) / CI_KC) : (1 << 30);
+                // first chunk with a non-zero history operand: a U block starts at its own diagonal block U_rho,rho, which is upper
+                // triangular -- the rows of unit wu are zero left of column 16 wu (the chunks before it are skipped, 5 % of the
+                // kernel's MFMAs)
+                cf[u] = act[u] ? (isM[u] ? 0 : (64 * rblk + 16 * wu) / CI_KC) : (1 << 30);
                 ub[u] = (isM[u] ? Lb : Ub) + (size_t)rowb[u] * ld;
             }
             // first chunk anybody in the workgroup needs: slot 0 of group 0 has the longest history

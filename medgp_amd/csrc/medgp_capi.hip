@@ -319,6 +319,8 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         // MFMA phase of the other); else 8 waves for the lowest latency per patient
         const int shape = c->cholinv_nw ? c->cholinv_nw : (nbatch > c->num_cu ? 44 : 84);
         if (shape == 44) hipLaunchKernelGGL((k_cholinv<4, 4>), dim3(nbatch), dim3(256), 0, stream, L, want_mode, 0);
+        else if (shape == 82) hipLaunchKernelGGL((k_cholinv<8, 2>), dim3(nbatch), dim3(512), 0, stream, L, want_mode, 0);
+        else if (shape == 42) hipLaunchKernelGGL((k_cholinv<4, 2>), dim3(nbatch), dim3(256), 0, stream, L, want_mode, 0);
         else hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, want_mode, 0);
     }
     int from_slab = 0;
