@@ -49,21 +49,39 @@ def alg_work(kernel, N, Q, D, H):
     return table.get(kernel, (0.0, 0.0, "hbm"))
 
 
+def csrc_digest():
+    """sha256 over the device sources (medgp_amd/csrc/*.h, *.hip): identifies the kernels a PMC summary was taken from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "medgp_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "medgp_amd", "csrc", "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel, P, N):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json:
-    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; bytes = counter x 1024, FETCH_SIZE doubled
-    for 16-byte-per-lane streams as MI355X_MICROARCH.md's HBM section prescribes).  PMC and kernel-trace cannot be
-    combined in one run, so the value is measured offline and only returned for the shape it was measured on."""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r02_pmc_summary.json: separate
+    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; bytes = counter x 1024, FETCH_SIZE doubled for
+    16-byte-per-lane streams as MI355X_MICROARCH.md's HBM section prescribes).  PMC and kernel-trace cannot be combined in
+    one run, so the value is measured offline.  It is returned only for the shape it was measured on AND only while the
+    device sources are byte-identical to the ones it was measured from (the summary records their digest and the git
+    commit); otherwise null -- a stale number is worse than none.  Returns (bytes or None, provenance dict)."""
+    prov = {"file": "profiles/r02_pmc_summary.json"}
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
     except (OSError, ValueError):
-        return None
+        return None, dict(prov, status="no PMC summary")
+    meta = d.get("_meta", {})
+    prov.update({"git_commit": meta.get("git_commit"), "csrc_sha256": (meta.get("csrc_sha256") or "")[:16]})
+    if meta.get("csrc_sha256") != csrc_digest():
+        return None, dict(prov, status="stale: device sources changed since the PMC passes")
     if (P, N) != (512, 512):
-        return None
+        return None, dict(prov, status="not measured for this shape")
     for name, v in d.items():
         if name.split("<")[0] == kernel and "derived" in v:
-            return v["derived"]["fetch_bytes_x2_if_wide_loads"] + v["derived"]["write_bytes"]
-    return None
+            return v["derived"]["fetch_bytes_x2_if_wide_loads"] + v["derived"]["write_bytes"], dict(prov, status="current")
+    return None, dict(prov, status="kernel not in the summary")
 
 
 def aggregate_time(t_local, world):
@@ -146,6 +164,53 @@ def cpu_baseline(D, N, Q, R, seed, budget_s=10.0):
                       f"oracle per-hyper gradient loop, OpenMP over hypers, {el:.1f} s"}
 
 
+def other_configs(dev_index, seed, reps=5):
+    """Short measurements of BASELINE configs 2, 3 and 5 on this GPU (outside the timed region of the headline; rank 0 at
+    N = 1 only).  Whole evaluations (nlml + gradient, host-pointer API, wall clock incl. the theta / result transfers);
+    `frac_fp64_peak` = F_alg x evaluations/s / 78.6 TFLOP/s with F_alg = N^3 + 6 N^2 + 80 Q N (N + 1) / 2."""
+    import medgp_amd
+    from medgp_amd import synth
+    out = {}
+    shapes = [
+        ("config2_256xN256_D2", 2, 256, 5, 2, 256, 0.0, False),
+        ("config3_1xN2048_D24", 24, 2048, 5, 8, 1, 0.0, False),
+        ("config3_batched_16xN2048_D24", 24, 2048, 5, 8, 16, 0.0, False),
+        ("config5_1xN4096_D64_sparse_prior2", 64, 4096, 5, 8, 1, 0.5, True),
+    ]
+    for name, D, N, Q, R, P, sparse, prior in shapes:
+        H = synth.num_hyp(7, Q, D, R)
+        ctx = medgp_amd.Context(7, Q, D, R, device=dev_index)
+        ctx.reserve(P, N, P)
+        nu = min(P, 8)
+        pts = [synth.patient(seed + 1, p, D, N) for p in range(nu)]
+        ths = [synth.theta(seed + 1, p, 7, Q, D, R, sparse_frac=sparse) for p in range(nu)]
+        ctx.set_patients(np.arange(P), [pts[s % nu] for s in range(P)])
+        th = np.stack([ths[s % nu] for s in range(P)])
+        if prior:
+            f, ty, ex, p0, p1 = synth.hier_gamma_prior(Q, D, R, 0.01)
+            ty = ty.copy()
+            ty[np.where(ths[0] == 0.0)[0]] = 0      # test-time clamp of the exactly-zero A entries (ref: c_prior.cpp:118-140)
+            ctx.set_prior(-1, f, ty, ex, p0, p1)
+        slots = np.arange(P)
+        nl, g, st = ctx.nlml_grad(slots, th, True)
+        assert np.all(st >= 0) and np.all(np.isfinite(nl)), name
+        ctx.nlml_grad(slots, th, True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.nlml_grad(slots, th, True)
+        dt = (time.perf_counter() - t0) / reps
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        ctx.nlml_grad(slots, th, True)
+        prof = {k: round(v[0], 4) for k, v in ctx.profile_read().items() if v[1] > 0}
+        ctx.profile_enable(False)
+        f_alg = N ** 3 + 6 * N * N + 80 * Q * N * (N + 1) / 2
+        out[name] = {"patients": P, "N": N, "D": D, "Q": Q, "R": R, "H": H, "ms_per_call": 1e3 * dt, "evals_per_s": P / dt,
+                     "frac_fp64_peak": f_alg * P / dt / 1e12 / FP64_PEAK_TFLOPS, "kernel_ms": prof}
+        ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +225,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prior", action="store_true")
     ap.add_argument("--flag-grad", type=int, default=1)
+    ap.add_argument("--no-extra", action="store_true", help="skip the short measurements of BASELINE configs 2, 3, 5")
     args = ap.parse_args()
 
     import torch
@@ -248,7 +314,8 @@ def main():
         else:
             achieved = byts * P / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
-        roof.update({"traffic": pmc_traffic(dom, P, N), "kernel": dom, "avg_launch_ms": avg_ms,
+        traffic, traffic_prov = pmc_traffic(dom, P, N)
+        roof.update({"traffic": traffic, "traffic_provenance": traffic_prov, "kernel": dom, "avg_launch_ms": avg_ms,
                      "alg_per_patient": {"flop": flop, "bytes": byts},
                      "kernel_ms_per_step": {k: round(v[0] / max(args.steps, 1), 4) for k, v in prof.items() if v[1] > 0}})
         f_alg = N ** 3 + 6 * N * N + 80 * Q * N * (N + 1) / 2
@@ -257,6 +324,8 @@ def main():
             "end_to_end": {"flop_per_eval": f_alg, "tflops": f_alg * value / world / 1e12,
                            "frac_fp64_peak": f_alg * value / world / 1e12 / FP64_PEAK_TFLOPS},
         }
+        if world == 1 and not args.no_extra and (P, N, D) == (512, 512, 24):
+            extra["other_configs"] = other_configs(local_rank, args.seed)
         if world == 1 and not args.no_cpu_baseline:
             extra["cpu_baseline"] = cpu_baseline(D, N, Q, R, args.seed)
         line = result_line(value, world, args.steps, args.warmup, 1e3 * t / args.steps,

@@ -31,7 +31,8 @@ class MedgpError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libmedgp_hip.so")
+    """The in-tree library; MEDGP_LIB selects another build of the SAME ABI (A/B measurements of kernel variants)."""
+    return os.environ.get("MEDGP_LIB") or os.path.join(_HERE, "libmedgp_hip.so")
 
 
 _lib = None

@@ -640,11 +640,12 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 if (wave == NW - 1) sm.zacc[lane] = zsum;
                 __syncthreads();
                 STAMP(0);   // wait for the slowest GEMM wave (folded into 0)
-#ifdef CI_DIAG_ONE_WAVE
+                // one wave factors the block while the co-resident workgroup's waves own the SIMDs (measured at 512 x N=512, two
+                // workgroups per CU: one-wave factor 1.52 ms, the four-wave diag_factor_wg 1.62 ms -- its barriers and the
+                // register traffic around the out-of-line call in all four waves cost more than its shorter critical path
+                // gains; one workgroup per CU: no difference).  The look-ahead multi-CU schedule, whose diagonal chain IS the
+                // critical path, uses diag_factor_wg.
                 if (wave == 0) diag_factor_wave((ld_t *)&sm.Dk[0][0], (ld_t *)&sm.Xk[0][0], (ld_t *)sm.rhs, (li_t *)&sm.fail, (ld_t *)&sm.logdet, lane);
-#else
-                diag_factor_wg((ld_t *)&sm.Dk[0][0], (ld_t *)&sm.Xk[0][0], (ld_t *)sm.rhs, (li_t *)&sm.fail, (ld_t *)&sm.logdet, wave, lane);
-#endif
                 if (wave == 0) {
                     STAMP(3);   // diagonal factor
                     if (!sm.fail) {

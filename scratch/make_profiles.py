@@ -1,10 +1,14 @@
-"""Regenerate profiles/r01_* from the rocprofv3 outputs of scratch/gpurun_prof.sh <tag> (gpurun_out/prof_<tag>_*)."""
-import csv, glob, collections, json, shutil, sys
+"""Regenerate profiles/<round>_* from the rocprofv3 outputs of scratch/gpurun_prof.sh <tag> (gpurun_out/prof_<tag>_*).
+usage: python scratch/make_profiles.py <tag> [round, default r02].  Records the git commit and the digest of the device
+sources the passes were taken from (bench.py refuses a stale traffic figure)."""
+import csv, glob, collections, json, os, shutil, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag = sys.argv[1]
-shutil.copy(glob.glob(f'gpurun_out/prof_{tag}_trace/runc/*_kernel_stats.csv')[0], 'profiles/r01_kernel_stats.csv')
-open('profiles/r01_bench_line_under_rocprof.json', 'w').write([l for l in open(f'gpurun_out/bench_{tag}_trace.log') if l.startswith('{')][-1])
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+shutil.copy(glob.glob(f'gpurun_out/prof_{tag}_trace/runc/*_kernel_stats.csv')[0], f'profiles/{rnd}_kernel_stats.csv')
+open(f'profiles/{rnd}_bench_line_under_rocprof.json', 'w').write([l for l in open(f'gpurun_out/bench_{tag}_trace.log') if l.startswith('{')][-1])
 try:
-    open('profiles/r01_bench_line.json', 'w').write([l for l in open(f'gpurun_out/bench_{tag}_plain.log') if l.startswith('{')][-1])
+    open(f'profiles/{rnd}_bench_line.json', 'w').write([l for l in open(f'gpurun_out/bench_{tag}_plain.log') if l.startswith('{')][-1])
 except OSError:
     pass
 out = {}
@@ -19,6 +23,7 @@ for t in ('fetch', 'write', 'mfma', 'sq'):
     for k, v in d.items():
         out.setdefault(k, {}).update({c: {"mean_per_launch": sum(x) / len(x), "launches": len(x)} for c, x in v.items()})
 for k, v in out.items():
+    if k == '_meta': continue
     if 'FETCH_SIZE' in v:
         f = v['FETCH_SIZE']['mean_per_launch'] * 1024
         w = v['WRITE_SIZE']['mean_per_launch'] * 1024
@@ -32,7 +37,11 @@ for k, v in out.items():
             "valu_wave_instructions": v['SQ_INSTS_VALU']['mean_per_launch'],
             "valu_issue_frac_of_1024_simds": v['SQ_INSTS_VALU']['mean_per_launch'] * 4 / (1024 * cyc),
             "wait_any_frac_of_wave_cycles": v['SQ_WAIT_ANY']['mean_per_launch'] / v['SQ_WAVE_CYCLES']['mean_per_launch'] if 'SQ_WAVE_CYCLES' in v else None})
-json.dump(out, open('profiles/r01_pmc_summary.json', 'w'), indent=1)
+import bench
+out['_meta'] = {'git_commit': subprocess.run(['git', 'rev-parse', 'HEAD'], capture_output=True, text=True).stdout.strip(),
+                'csrc_sha256': bench.csrc_digest(), 'command': 'python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra (one rocprofv3 --pmc pass per counter group)'}
+json.dump(out, open(f'profiles/{rnd}_pmc_summary.json', 'w'), indent=1)
 for k, v in out.items():
+    if k == '_meta': continue
     print(k, {a: (round(b, 3) if isinstance(b, float) and b < 10 else int(b)) for a, b in v.get('derived', {}).items()})
-print(open('profiles/r01_kernel_stats.csv').read()[:1100])
+print(open(f'profiles/{rnd}_kernel_stats.csv').read()[:1100])
