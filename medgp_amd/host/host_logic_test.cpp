@@ -169,8 +169,86 @@ static int test_scg() {
     return bad;
 }
 
+// ---- optdump: the product's state machines on analytic objectives, results dumped for the Python restatements of the
+//      reference's optimisers (oracle/optimizer_oracle.py; tests/test_optimizer_oracle.py compares bit for bit).
+//      Objectives use + - * / sqrt log only, so C++ and Python evaluate them identically.
+static bool poly(const vec &x, double &f, vec &g) {   // coupled quartic: not separable, several line-search regimes
+    const size_t n = x.size();
+    f = 0; g.assign(n, 0.0);
+    double sum = 0;
+    for (size_t i = 0; i < n; i++) sum += x[i];
+    for (size_t i = 0; i < n; i++) {
+        const double w = 1.0 + 0.5 * (double)i, c = 0.25 * (double)i - 1.0, d = x[i] - c;
+        f += 0.5 * w * d * d + 0.05 * d * d * d * d;
+        g[i] = w * d + 0.2 * d * d * d;
+    }
+    f += 0.05 * sum * sum;
+    for (size_t i = 0; i < n; i++) g[i] += 0.1 * sum;
+    return true;
+}
+static void dump_vec(FILE *f, const vec &v) { fwrite(v.data(), 8, v.size(), f); }
+static int opt_dump(const char *path) {
+    FILE *fo = fopen(path, "wb");
+    if (!fo) return 1;
+    // SCG cases: [n_eval, loss, X...]
+    struct Case { int id; objective_t obj; vec init; int budget; };
+    std::vector<Case> cases = {
+        {0, quad, vec(6, 2.0), -100}, {0, quad, vec(6, 2.0), -7}, {0, quad, vec(6, 2.0), 5},
+        {1, rosen, {-1.2, 1.0, -0.5, 0.8}, -100}, {1, rosen, {-1.2, 1.0, -0.5, 0.8}, -37},
+        {2, hole, {2.4, 3.9, 0.0}, -60}, {3, poly, {1.5, -2.0, 0.7, 3.0, -0.4}, -80},
+    };
+    for (auto &c : cases) {
+        double l; vec X;
+        const int n = run_machine(c.budget, c.init, c.obj, l, X);
+        vec head = {(double)c.id, (double)c.budget, (double)n, l};
+        dump_vec(fo, head); dump_vec(fo, X);
+    }
+    // variational EM: Q = 2, D = 2, R = 2; theta = [lik (D) | A (QDR) | mu, v (2Q) | kappa (QD)]; objective = poly + the linked
+    // Normal priors of the A entries as the reference's objective applies them (ref: inference/c_inference_prior.cpp:60-150,
+    // prior/c_prior.cpp:383-421: lp = -(a - m)^2 / (2 v) - log(2 pi v) / 2, nlml -= lp, grad += (a - m) / v; clamp: grad = 0)
+    for (int variant = 0; variant < 2; variant++) {
+        const int Q = 2, D = 2, R = 2, nlik = D, H = D + Q * (D * R + 2 + D);
+        c_prior prior(Q * (D * R + 2 + D), 0, D);
+        prior.setup_param(7, {Q, D, R}, 2, {variant ? 0.3f : 0.01f, 0.01f});
+        vec init(H);
+        for (int h = 0; h < H; h++) init[h] = 0.3 * (double)((h * 7) % 5) - 0.6;
+        if (variant) { init[nlik + 1] = 0.0; init[nlik + 6] = 0.0; }   // exactly-zero A entries: psi == 0 -> clamped (ref :151-154)
+        varem_machine m;
+        m.start(-6, init, &prior, {Q, D, R}, nlik, 15, false);
+        int nev = 0;
+        const double PI = 3.14159265;
+        while (!m.done()) {
+            vec th = m.request(), g;
+            double f = 0;
+            poly(th, f, g);
+            if (variant) { g[nlik + 1] = 0.0; g[nlik + 6] = 0.0; }   // two A entries the data say nothing about: they stay exactly 0
+            for (int a = 0; a < Q * D * R; a++) {
+                const int h = nlik + a;
+                if (!prior.flag_cov[a]) continue;
+                if (prior.type_cov[a] == 0) { g[h] = 0.0; continue; }
+                const double mean = (double)prior.fix_param_cov[a][0], var = (double)prior.fix_param_cov[a][1];
+                const double lp = -1.0 * (th[h] - mean) * (th[h] - mean) / (2.0 * var) - std::log(2 * PI * var) / 2.0;
+                f -= lp;
+                g[h] -= -1.0 * (th[h] - mean) / var;
+            }
+            nev++;
+            m.feed(true, f, g);
+            (void)m.prior_changed();
+        }
+        vec head = {(double)(100 + variant), (double)nev, m.opt_loss};
+        dump_vec(fo, head); dump_vec(fo, m.opt_parameter); dump_vec(fo, prior.get_cov_varEM_all());
+        vec types;
+        for (int a = 0; a < Q * D * R; a++) types.push_back((double)prior.type_cov[a]);
+        dump_vec(fo, types);
+    }
+    fclose(fo);
+    printf("OPTDUMP ok\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "scg")) return test_scg();
+    if (argc >= 3 && !strcmp(argv[1], "optdump")) return opt_dump(argv[2]);
     if (argc >= 4 && !strcmp(argv[1], "hyp")) {
         c_experiment e;
         if (!e.load(argv[2])) { printf("ERROR: %s\n", e.error().c_str()); return 1; }

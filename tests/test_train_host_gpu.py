@@ -72,3 +72,82 @@ def test_train_skips_patient_with_too_few_samples(tmp_path, built_lib):
     assert open(os.path.join(ex["dirs"]["train"], "train_flag_P009.txt")).read() == "0\n"   # ref main_one_train.cpp:185-201
     assert open(os.path.join(ex["dirs"]["train"], "train_num_P009.txt")).read() == "3\n"
     assert not os.path.exists(os.path.join(ex["dirs"]["train"], "train_hyp_P009.bin"))
+
+
+@pytest.mark.parametrize("prior_index", [2, 0])
+def test_train_vs_reference_optimiser_restatement(tmp_path, built_lib, prior_index):
+    """Rows f1 / f2 against an INDEPENDENT oracle: the screening arg-min (main_one_train.cpp:228-253) and the optimiser run
+    (:258-300; c_optimizer_scg / c_optimizer_varEM restated in oracle/optimizer_oracle.py) driven by the CPU oracle's
+    nlml + gradient, compared with the files medgp_train writes.  Same initial points (the glibc rand() draws are dumped by
+    host_logic_test), same evaluation budgets; the two objective implementations agree to ~1e-14, the line searches take
+    the same decisions, and the trained hypers agree far below the 1e-6 the north star asks of the objective itself."""
+    from oracle import optimizer_oracle as OO
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", HOST, "medgp_train"])
+    logic = os.path.join(HOST, "host_logic_test")
+    if not os.path.exists(logic):
+        subprocess.check_call(["make", "-s", "-C", HOST, "host_logic_test"])
+    pans = ["P001", "P002", "P003"]
+    Ns = [60, 75, 48]
+    Q, D, R = 3, 2, 2
+    H = D + Q * (D * R + 2 + D)
+    # variational EM: ONE outer iteration (100 evaluations + the closed-form update).  Longer runs are not comparable point
+    # by point: weakly determined A entries are shrunk towards zero by the sparse prior, and 1e-14 differences between the two
+    # objective implementations grow to 1e-2 in those entries over 300 evaluations (observed); the state machines themselves
+    # are compared bit for bit over several outer iterations on analytic objectives (tests/test_optimizer_oracle.py).
+    opt = {"top_iteration_num": 1} if prior_index == 2 else {"top_iteration_num": 40}   # prior 0: 40 SCG evaluations
+    ex = make_experiment(tmp_path / "e", pans, D=D, Q=Q, R=R, N=Ns, prior_index=prior_index, opt=opt)
+    for pan in pans:
+        run(["--cfg", ex["cfg"], "--pan", pan, "--thread", "1"])
+    hb = tmp_path / "hyp.bin"
+    subprocess.check_call([logic, "hyp", ex["cfg"], str(hb)], stdout=subprocess.DEVNULL)
+    inits = np.fromfile(hb, np.float64).reshape(ex["opt"]["random_init_num"], H)
+    for pan in pans:
+        db = tmp_path / f"data_{pan}.bin"
+        subprocess.check_call([logic, "data", ex["cfg"], pan, str(db)], stdout=subprocess.DEVNULL)
+        raw = open(db, "rb").read()
+        n = int(np.frombuffer(raw, np.int32, 1)[0])
+        m = np.frombuffer(raw, np.int32, n, 4).copy()
+        t = np.frombuffer(raw, np.float32, n, 4 + 4 * n).copy()
+        y = np.frombuffer(raw, np.float32, n, 4 + 8 * n).copy()
+        # ---- f2: screening, nlml only, no prior yet (prior set up after it, main_one_train.cpp:222-226, :258-264)
+        best, best_init = np.inf, None
+        for th in inits:
+            r = O.nlml_grad(7, Q, D, R, m, t, y, th, flag_grad=False)
+            assert r["ok"]
+            if r["nlml"] < best:
+                best, best_init = r["nlml"], th
+        got_init = np.fromfile(os.path.join(ex["dirs"]["train"], "train_init_hyp_" + pan + ".bin"), np.float64)
+        assert np.array_equal(got_init, best_init), pan
+        # ---- f1: the optimiser
+        nev = [0]
+
+        def objective(pr):
+            def obj(th):
+                nev[0] += 1
+                r = O.nlml_grad(7, Q, D, R, m, t, y, np.asarray(th, np.float64), flag_grad=True, prior=pr)
+                if not r["ok"]:
+                    return False, 0.0, []
+                return True, r["nlml"], list(r["grad"])
+            return obj
+
+        budget = -ex["opt"]["top_iteration_num"]
+        if prior_index == 2:
+            vp = OO.VarEMPrior(Q, D, R, 0.01)
+
+            def obj_of_prior(v):
+                pr = O.Prior.hier_gamma(Q, D, R, 0.01, 0.01)
+                a0 = D
+                pr.type[a0:a0 + Q * D * R] = np.array(v.type_A, np.int32)
+                pr.p1[a0:a0 + Q * D * R] = np.array(v.var_A, np.float32)
+                return objective(pr)
+            loss, theta, _ = OO.varem(budget, best_init, obj_of_prior, vp, D, ex["opt"]["iteration_num_per_update"])
+            var = np.fromfile(os.path.join(ex["dirs"]["train"], "train_var_hyp_" + pan + ".bin"), np.float64)
+            print(pan, "varEM state max abs diff", np.abs(var - np.array(vp.cov_varEM)).max())
+            np.testing.assert_allclose(var, np.array(vp.cov_varEM), rtol=1e-4, atol=1e-6)
+        else:
+            loss, theta, _ = OO.scg(budget, best_init, objective(None))
+        got = np.fromfile(os.path.join(ex["dirs"]["train"], "train_hyp_" + pan + ".bin"), np.float64)
+        err = np.abs(got - np.array(theta)) / np.maximum(1.0, np.abs(theta))
+        print(pan, "theta max err", float(err.max()), "evaluations", nev[0])
+        assert err.max() <= 1e-6, (pan, float(err.max()))
