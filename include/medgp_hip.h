@@ -141,6 +141,16 @@ int medgp_get_factor(medgp_ctx *ctx, int b, float *alpha, float *linv, float *be
 int medgp_fit_predict(medgp_ctx *ctx, int slot, const double *theta, int nstar, const int32_t *meta2,
                       const float *t2, float *mean, float *var, int32_t *status);
 
+/* Cholesky factor of one patient's Gram matrix and z = L^-1 (y - m), fp64, in the CALLER's observation order:
+ * L [n*n] row-major lower (strict upper zero), z [n]; either may be NULL.  This is the state LAPACKE_spotrf + the first
+ * half of spotrs leave inside c_inference_exact::compute_nlml (ref: inference/c_inference_exact.cpp:96-125) before it is
+ * turned into chol_alpha / chol_factor_inv.  It is what the online imputation loop can SHARE between its problems: with the
+ * observations in time order every training subset `past(t)` of main_one_test.cpp:287-300 is a leading block of one
+ * factorisation (L[0:p, 0:p] is the factor of the first p observations, z[0:p] their solve), and the same-time observations
+ * appended at :358-365 are the next rows -- medgp_test's no-update pass does one medgp_factor per patient instead of one
+ * factorisation per imputed observation.  status as medgp_nlml_grad (no n > 2 guard, like GP_Regression::train). */
+int medgp_factor(medgp_ctx *ctx, int slot, const double *theta, double *L, double *z, int32_t *status);
+
 /* nbatch independent (train(false) + predict ONE point) problems in one call: problem b uses patient
  * slots[b], hypers theta[b*H..), test point (meta2[b], t2[b]).  This is the inner body of the online
  * imputation loop, ref: main_one_test.cpp:352-409 (N* = 1 there, :369-372), batched over the (time stamp,

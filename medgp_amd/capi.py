@@ -21,7 +21,7 @@ SYMBOLS = [
     "medgp_abi_version", "medgp_device_count", "medgp_create", "medgp_destroy", "medgp_last_error",
     "medgp_num_hyp", "medgp_set_pi", "medgp_set_stream", "medgp_reserve", "medgp_set_patient",
     "medgp_set_patients", "medgp_set_prior", "medgp_nlml_grad", "medgp_nlml_grad_device", "medgp_get_factor",
-    "medgp_fit_predict", "medgp_fit_predict_batch", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
+    "medgp_factor", "medgp_fit_predict", "medgp_fit_predict_batch", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
     "medgp_profile_kernel_name", "medgp_profile_read", "medgp_profile_reset",
 ]
 
@@ -74,6 +74,7 @@ def load():
     lib.medgp_nlml_grad.argtypes = [vp, C.c_int, i32p, dp, C.c_int, dp, dp, i32p]
     lib.medgp_nlml_grad_device.argtypes = [vp, C.c_int, i32p, vp, C.c_int, vp, vp, vp]
     lib.medgp_get_factor.argtypes = [vp, C.c_int, fp, fp, fp]
+    lib.medgp_factor.argtypes = [vp, C.c_int, dp, dp, dp, i32p]
     lib.medgp_fit_predict.argtypes = [vp, C.c_int, dp, C.c_int, i32p, fp, fp, fp, i32p]
     lib.medgp_fit_predict_batch.argtypes = [vp, C.c_int, i32p, dp, i32p, fp, fp, fp, i32p]
     lib.medgp_synchronize.argtypes = [vp]
@@ -189,6 +190,15 @@ class Context:
         beta = C.c_float()
         self._chk(self._lib.medgp_get_factor(self._h, int(b), _ptr(alpha, C.c_float), _ptr(linv, C.c_float), C.byref(beta)))
         return alpha, linv, beta.value
+
+    def factor(self, slot, theta, n):
+        """Cholesky factor (caller order, lower, fp64) and z = L^-1 y of one patient. Returns (L[n,n], z[n], status)."""
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        Lm = np.zeros((n, n))
+        z = np.zeros(n)
+        st = C.c_int32()
+        self._chk(self._lib.medgp_factor(self._h, int(slot), _ptr(theta, C.c_double), _ptr(Lm, C.c_double), _ptr(z, C.c_double), C.byref(st)))
+        return Lm, z, st.value
 
     def fit_predict(self, slot, theta, meta2, t2):
         theta = np.ascontiguousarray(theta, dtype=np.float64)

@@ -63,6 +63,8 @@ struct medgp_ctx {
     double *d_la_part = nullptr, *d_la_small = nullptr;
     size_t la_part_cap = 0, la_small_cap = 0;
     int mc_old = 0;           // MEDGP_MC_OLD=1: the first multi-CU schedule (two launches per step), kept for A/B runs
+    char *h_bounce = nullptr;        // pinned bounce buffer for the large device-to-host exports (factor matrices)
+    size_t bounce_cap = 0;
     int *d_one_slot = nullptr;       // single-entry slot table for the caller-order re-factorisation of medgp_get_factor
     // predict scratch
     double *d_t2 = nullptr, *d_ks = nullptr;
@@ -188,6 +190,21 @@ int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bo
 }
 
 inline int tri(int n) { return n * (n + 1) / 2; }
+
+// device -> host copy of `bytes` through a pinned bounce buffer (a pageable hipMemcpy of this size pays ~10 ms of one-time
+// runtime staging set-up on its first use); returns the pinned pointer, valid until the next call
+int d2h_pinned(medgp_ctx *c, const void *dev, size_t bytes, const char **out) {
+    if (bytes > c->bounce_cap) {
+        if (c->h_bounce) (void)hipHostFree(c->h_bounce);
+        c->h_bounce = nullptr; c->bounce_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_bounce, bytes + bytes / 4, hipHostMallocDefault));
+        c->bounce_cap = bytes + bytes / 4;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_bounce, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *out = c->h_bounce;
+    return MEDGP_OK;
+}
 
 // scratch of the look-ahead factorisation for `nbatch` entries of at most `nbmax` 64-blocks (freed by free_all)
 int ensure_la(medgp_ctx *c, int nbatch, int nbmax, LaArgs *out) {
@@ -470,6 +487,7 @@ void medgp_destroy(medgp_ctx *c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_bounce) (void)hipHostFree(c->h_bounce);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -814,8 +832,10 @@ int medgp_get_factor(medgp_ctx *c, int b, float *alpha, float *linv, float *beta
         *beta = (float)sc[1];
     }
     if (linv) {
-        std::vector<double> hx((size_t)n * ld);
-        HIPCHK(c, hipMemcpy(hx.data(), c->dev.Linv + (size_t)b * ld * ld, sizeof(double) * n * ld, hipMemcpyDeviceToHost));
+        const char *hp = nullptr;
+        int rc2 = d2h_pinned(c, c->dev.Linv + (size_t)b * ld * ld, sizeof(double) * n * ld, &hp);
+        if (rc2) return rc2;
+        const double *hx = (const double *)hp;
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++)   // device holds U = L^-T: (L^-1)[i][j] = U[j][i]; strict upper zeroed as ref c_inference_exact.cpp:139-143
                 linv[(size_t)i * n + j] = (j <= i) ? (float)hx[(size_t)j * ld + i] : 0.0f;
@@ -868,6 +888,36 @@ static int fit_predict_impl(medgp_ctx *c, int nbatch, const int32_t *slots, cons
     HIPCHK(c, hipMemcpyAsync(var, c->d_var, sizeof(float) * ntot, hipMemcpyDeviceToHost, c->stream));
     if (status) HIPCHK(c, hipMemcpyAsync(status, c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MEDGP_OK;
+}
+
+int medgp_factor(medgp_ctx *c, int slot, const double *theta, double *Lout, double *zout, int32_t *status) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (!theta) return fail(c, MEDGP_ERR_ARG, "theta is NULL");
+    if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t s1 = slot;
+    int max_n = 0, rc;
+    if ((rc = set_batch(c, 1, &s1, &max_n, true))) return rc;       // the CALLER's observation order
+    const int n = c->h_n[slot], ld = c->ldn;
+    HIPCHK(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * c->H, hipMemcpyHostToDevice, c->stream));
+    if ((rc = run_pipeline(c, 1, max_n, c->d_theta, 0, false, 1, nullptr, nullptr, nullptr, false))) return rc;
+    int st = 0;
+    HIPCHK(c, hipMemcpyAsync(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (status) *status = st;
+    if (st < 0) return MEDGP_OK;
+    if (Lout && n > 0) {
+        const char *hp = nullptr;
+        if ((rc = d2h_pinned(c, c->dev.Kmat, sizeof(double) * n * ld, &hp))) return rc;
+        const double *hl = (const double *)hp;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) Lout[(size_t)i * n + j] = (j <= i) ? hl[(size_t)i * ld + j] : 0.0;
+    }
+    if (zout && n > 0) {
+        HIPCHK(c, hipMemcpyAsync(zout, c->dev.z, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return MEDGP_OK;
 }
 

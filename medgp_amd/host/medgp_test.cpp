@@ -11,6 +11,7 @@
 // medgp_fit_predict_batch (each problem = its own patient slot holding the training subset).
 // Outputs (:447-472): test_<mode>_{feature,ci,flag}_<PAN>.txt, test_<mode>_{etime,error,pred}_<PAN>.bin.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -37,7 +38,7 @@ struct Problem {
 };
 
 bool run_test_one(c_experiment &curr_exp, medgp_ctx *ctx, const string &PAN, int fold, bool flag_update,
-                  const string &output_prefix, const string &alg, const vector<int> &test_kernel_param, int max_batch) {
+                  const string &output_prefix, const string &alg, const vector<int> &test_kernel_param, int max_batch, bool per_problem) {
     cout << "running online imputation: " << (flag_update ? "with online updating" : "without online updating") << endl;
     cout << "testing patinet: " << PAN << " in cross-validation fold " << fold << endl;
     vector<int> meta_array;
@@ -128,11 +129,84 @@ bool run_test_one(c_experiment &curr_exp, medgp_ctx *ctx, const string &PAN, int
             }
         }
 
-        // ---- pass 2: all imputation problems, batched
+        // ---- pass 2: all imputation problems
+        const auto t_pass2 = std::chrono::steady_clock::now();
         const int np = (int)problems.size();
         vector<float> pmean(np, 0.f), pvar(np, 0.f);
         vector<int32_t> pstat(np, -2);   // -2: no training observations
-        for (int c0 = 0; c0 < np; c0 += max_batch) {
+        bool shared_done = false;
+        if (!flag_update && !per_problem) {
+            // Without online updating every problem uses the SAME hypers and its training set is `all observations before the
+            // time stamp` + `the other observations AT the time stamp` (ref :287-300, :358-365).  With the observations in time
+            // order that is a leading block of ONE Gram matrix plus the next rows: a single factorisation of the whole patient
+            // (medgp_factor) holds every prefix factor (L[0:p,0:p]), every prefix solve (z[0:p]) and, in the rows of the c
+            // observations of a time stamp, their conditional covariance given the past, G = L_cc L_cc^T, and their residuals
+            // r = L_cc z_c.  Each imputation is then the Gaussian conditional of one component of N(y_c - r, G) given the
+            // others: O(c^3) host work instead of one O(N^3) factorisation per observation.  Same mathematics as the
+            // reference (train(false) + predict on each subset), different association; outputs are float either way.
+            vector<int> order(n_all);
+            for (int i = 0; i < n_all; i++) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return time_array[a] < time_array[b]; });
+            vector<int32_t> sm(n_all); vector<float> st(n_all), sy(n_all);
+            for (int i = 0; i < n_all; i++) { sm[i] = meta_array[order[i]]; st[i] = time_array[order[i]]; sy[i] = value_array[order[i]]; }
+            vector<double> Lf((size_t)n_all * n_all), zf(n_all);
+            int32_t fst = -1;
+            if (medgp_set_patient(ctx, 0, n_all, kidx == 7 ? sm.data() : nullptr, st.data(), sy.data()) ||
+                medgp_factor(ctx, 0, mode_parameter.data(), Lf.data(), zf.data(), &fst)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
+            cout << "INFO: upload + shared factorisation " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pass2).count() << " ms" << endl;
+            if (fst == 0) {   // a jittered or failed factorisation is not shared: the reference would jitter each subset on its own
+                vector<int> pos_of(n_all);
+                for (int i = 0; i < n_all; i++) pos_of[order[i]] = i;
+                int k = 0;
+                for (int tt = 0; tt < (int)uniq.size(); tt++) {
+                    const vector<int> &curr = curr_of_tt[tt];
+                    const int c = (int)curr.size(), p = c ? pos_of[curr[0]] : 0;   // stable sort: curr occupies positions p .. p+c-1 in order
+                    vector<double> G((size_t)c * c, 0.0), r(c, 0.0);
+                    for (int a = 0; a < c; a++) {
+                        for (int b = 0; b <= a; b++) {
+                            double s = 0.0;
+                            for (int q = 0; q <= b; q++) s += Lf[(size_t)(p + a) * n_all + p + q] * Lf[(size_t)(p + b) * n_all + p + q];
+                            G[(size_t)a * c + b] = G[(size_t)b * c + a] = s;
+                        }
+                        double s = 0.0;
+                        for (int q = 0; q <= a; q++) s += Lf[(size_t)(p + a) * n_all + p + q] * zf[p + q];
+                        r[a] = s;
+                    }
+                    for (int jj = 0; jj < c; jj++, k++) {
+                        if (p == 0 && c == 1) continue;            // no training observations: stays -2
+                        const int m1 = c - 1;
+                        // S = G[sub,sub] = C C^T;  w = S^-1 r_sub,  u = S^-1 g,  g = G[sub,jj]
+                        vector<double> C((size_t)m1 * m1, 0.0), g(m1), rs(m1);
+                        vector<int> sub;
+                        for (int a = 0; a < c; a++) if (a != jj) sub.push_back(a);
+                        bool ok = true;
+                        for (int a = 0; a < m1 && ok; a++) {
+                            g[a] = G[(size_t)sub[a] * c + jj]; rs[a] = r[sub[a]];
+                            for (int b = 0; b <= a; b++) {
+                                double s = G[(size_t)sub[a] * c + sub[b]];
+                                for (int q = 0; q < b; q++) s -= C[(size_t)a * m1 + q] * C[(size_t)b * m1 + q];
+                                if (a == b) { if (!(s > 0.0)) { ok = false; break; } C[(size_t)a * m1 + a] = std::sqrt(s); }
+                                else C[(size_t)a * m1 + b] = s / C[(size_t)b * m1 + b];
+                            }
+                        }
+                        if (!ok) { pstat[k] = -1; continue; }
+                        // forward solves  C a1 = g,  C a2 = r_sub;  mean = (y - r_jj) + a1 . a2,  var = G_jj - a1 . a1
+                        vector<double> a1(m1), a2(m1);
+                        for (int a = 0; a < m1; a++) {
+                            double s1 = g[a], s2 = rs[a];
+                            for (int q = 0; q < a; q++) { s1 -= C[(size_t)a * m1 + q] * a1[q]; s2 -= C[(size_t)a * m1 + q] * a2[q]; }
+                            a1[a] = s1 / C[(size_t)a * m1 + a]; a2[a] = s2 / C[(size_t)a * m1 + a];
+                        }
+                        double mean = (double)value_array[curr[jj]] - r[jj], var = G[(size_t)jj * c + jj];
+                        for (int a = 0; a < m1; a++) { mean += a1[a] * a2[a]; var -= a1[a] * a1[a]; }
+                        pmean[k] = (float)mean; pvar[k] = (float)var; pstat[k] = 0;
+                    }
+                }
+                shared_done = true;
+                cout << "finish testing " << np << "/" << np << " imputations (one shared factorisation)" << endl;
+            }
+        }
+        for (int c0 = 0; c0 < np && !shared_done; c0 += max_batch) {
             vector<int32_t> slots, meta2, which;
             vector<float> t2;
             vector<double> thetas;
@@ -164,6 +238,8 @@ bool run_test_one(c_experiment &curr_exp, medgp_ctx *ctx, const string &PAN, int
             cout << "finish testing " << std::min(np, c0 + max_batch) << "/" << np << " imputations" << endl;
         }
 
+        cout << "INFO: " << np << " imputations in " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pass2).count()
+             << " ms (" << (shared_done ? "one shared factorisation" : "one factorisation per imputed observation, batched") << ")" << endl;
         // ---- outputs in the reference's order (ref :376-444)
         vector<int> out_feature, out_ci;
         vector<double> out_etime, out_error, out_pred;
@@ -207,6 +283,7 @@ bool run_test_one(c_experiment &curr_exp, medgp_ctx *ctx, const string &PAN, int
 int main(int argc, const char *argv[]) {
     string exp_cfg, PAN, alg;
     int thread_num = 1, fold = 0, device = 0, max_batch = 0;
+    bool per_problem = false;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--cfg") && i + 1 < argc) exp_cfg = argv[++i];
         else if (!strcmp(argv[i], "--pan") && i + 1 < argc) PAN = argv[++i];
@@ -215,6 +292,7 @@ int main(int argc, const char *argv[]) {
         else if (!strcmp(argv[i], "--kernclust-alg") && i + 1 < argc) alg = argv[++i];
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--max-batch") && i + 1 < argc) max_batch = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--per-problem")) per_problem = true;   // one factorisation per imputed observation in both passes (A/B)
         else { cout << "Error: unknown argument: " << argv[i] << endl; return 1; }
     }
     if (exp_cfg.empty() || PAN.empty() || alg.empty()) {
@@ -240,10 +318,35 @@ int main(int argc, const char *argv[]) {
     if (medgp_create(&ctx, device, kidx, test_kernel_param[0], test_kernel_param[1], test_kernel_param[2])) { cout << "ERROR: " << medgp_last_error(nullptr) << endl; return 1; }
     if (medgp_reserve(ctx, max_batch, n, max_batch)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
 
+    {   // first-use costs of the device (module load, first launches) are not part of either pass
+        vector<double> th0(medgp_num_hyp(ctx), 0.0);
+        int32_t s0 = 0, st0 = 0;
+        double f0 = 0.0;
+        if (!t.empty() && !medgp_set_patient(ctx, 0, (int)t.size(), kidx == 7 ? (const int32_t *)m.data() : nullptr, t.data(), y.data()))
+            (void)medgp_nlml_grad(ctx, 1, &s0, th0.data(), 0, &f0, nullptr, &st0);
+        vector<double> Lw((size_t)t.size() * t.size()), zw(t.size());
+        if (!t.empty()) (void)medgp_factor(ctx, 0, th0.data(), Lw.data(), zw.data(), &st0);
+        if (!t.empty()) {   // a full-size batch of the per-problem path: grows the staging / scratch buffers once
+            const int nbw = max_batch, nw = (int)t.size();
+            vector<int32_t> sl(nbw), pm, m2(nbw, m.empty() ? 0 : m[0]), stw(nbw);
+            vector<float> pt, py, t2w(nbw, t[0]), mw(nbw), vw(nbw);
+            vector<int64_t> off(1, 0);
+            vector<double> thw;
+            for (int b = 0; b < nbw; b++) {
+                sl[b] = b;
+                pm.insert(pm.end(), m.begin(), m.end()); pt.insert(pt.end(), t.begin(), t.end()); py.insert(py.end(), y.begin(), y.end());
+                off.push_back((int64_t)pt.size());
+                thw.insert(thw.end(), th0.begin(), th0.end());
+            }
+            (void)nw;
+            if (!medgp_set_patients(ctx, nbw, sl.data(), off.data(), kidx == 7 ? pm.data() : nullptr, pt.data(), py.data()))
+                (void)medgp_fit_predict_batch(ctx, nbw, sl.data(), thw.data(), m2.data(), t2w.data(), mw.data(), vw.data(), stw.data());
+        }
+    }
     time_t t1, t2;
     time(&t1);
-    bool ok = run_test_one(curr_exp, ctx, PAN, fold, false, "mean_wo_update", alg, test_kernel_param, max_batch) &&
-              run_test_one(curr_exp, ctx, PAN, fold, true, "mean_w_update", alg, test_kernel_param, max_batch);
+    bool ok = run_test_one(curr_exp, ctx, PAN, fold, false, "mean_wo_update", alg, test_kernel_param, max_batch, per_problem) &&
+              run_test_one(curr_exp, ctx, PAN, fold, true, "mean_w_update", alg, test_kernel_param, max_batch, per_problem);
     medgp_destroy(ctx);
     time(&t2);
     cout << "Finish all jobs. Total elapsed time = " << difftime(t2, t1) << " seconds" << endl;

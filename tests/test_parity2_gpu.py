@@ -274,3 +274,25 @@ def test_packed_upload_equals_single_uploads():
     with pytest.raises(medgp_amd.MedgpError):
         b.set_patients([0, 9], pts[:2])
     a.close(); b.close()
+
+
+def test_medgp_factor_caller_order_and_prefix_property():
+    """medgp_factor: L (lower, fp64) and z = L^-1 y in the CALLER's order; with time-ordered observations the leading
+    p x p block / first p entries are the factor / solve of the first p observations -- the property medgp_test's shared
+    imputation pass rests on (ref: main_one_test.cpp:287-300 training subsets `all observations before t`)."""
+    D, Q, R, N = 3, 3, 2, 150
+    m, t, y = synth.patient(33, 0, D, N, interleave=True)
+    o = np.argsort(t, kind="stable")
+    m, t, y = m[o], t[o], y[o]                       # time order: not grouped by output
+    th = synth.theta(33, 0, 7, Q, D, R)
+    ctx = make_ctx(7, Q, D, R, [(m, t, y)])
+    Lm, z, st = ctx.factor(0, th, N)
+    assert st == 0 and np.all(np.triu(Lm, 1) == 0)
+    K = O.gram(7, Q, D, R, m, t, th)
+    np.testing.assert_allclose(Lm @ Lm.T, K, rtol=0, atol=1e-12 * np.abs(K).max())
+    np.testing.assert_allclose(Lm @ z, y.astype(np.float64), rtol=0, atol=1e-12)
+    for p in (1, 40, 97):
+        Lp = np.linalg.cholesky(K[:p, :p])
+        np.testing.assert_allclose(Lm[:p, :p], Lp, rtol=0, atol=1e-11 * np.abs(Lp).max())
+        np.testing.assert_allclose(z[:p], np.linalg.solve(Lp, y[:p].astype(np.float64)), rtol=0, atol=1e-10)
+    ctx.close()
