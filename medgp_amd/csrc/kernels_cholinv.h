@@ -30,6 +30,12 @@ typedef __attribute__((address_space(1))) v2d gv2d_t;
 typedef __attribute__((address_space(3))) double ld_t;
 typedef __attribute__((address_space(3))) v2d lv2d_t;
 typedef __attribute__((address_space(3))) int li_t;
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v2d ci_bload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    union { v4i i; v2d d; } cv;
+    cv.i = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return cv.d;
+}
 
 #ifndef CI_KC
 #define CI_KC 16          // k-columns staged per barrier; the history operand is loaded 16 columns at a time
@@ -65,9 +71,12 @@ struct CholInvSmem {
         double Dk[64][66];             // diagonal phase: in D, out L_kk (lower)
         double St[NW][16 * UPW][CI_ST];   // panel store: per-wave (16 UPW) x 16 slab that turns row-contiguous
                                        // 16-byte global accesses into the transposed accumulator layout
+        struct {                       // end of the history GEMM of pass 0: the waves' partial z products, behind Dk
+            double dk_shadow[64][66];
+            double zpart[NW][64];
+        } zp;
     };
     double Xk[64][66];             // L_kk^-1 (lower, exact zeros above the diagonal)
-    double zacc[64];               // L[C_k, 0:64k] z[0:64k]
     alignas(16) double rhs[64 + 128];          // diag(L_kk) during the factor (+ 128 doubles of diag16 scratch), then the z right-hand side
     double zk[64];                 // z of the current panel (for the in-step alpha accumulation)
     double zs[1024];               // z history kept in LDS for n <= 1024: the in-loop z product then issues no
@@ -420,34 +429,55 @@ __device__ __attribute__((noinline)) void diag_factor_wg(ld_t *D, ld_t *X, ld_t 
 #define CI_EXP_SCALE(x) (x)
 #endif
 // One phase of the chunk loop: chunks [lo, hi) during which exactly the first NA units of this wave are active.
+// One phase of the chunk loop: chunks [lo, hi) during which exactly the first NA units of this wave are active.
+// Software pipeline (CI_KC = 16 columns per chunk = two 8-column halves):
+//   * the history operand of the NEXT chunk is requested half by half as soon as the MFMAs that read the registers of that
+//     half have been issued -- hc[u][0] right after half 0 (the 32 MFMAs of half 1 cover the request), hc[u][1] after half 1
+//     (the staging store, the barrier and the next chunk's half 0 cover it).  No extra registers: the loads go back into
+//     the registers their half has just released.  (Requested at the top of the chunk that consumes them, as before, the
+//     first MFMA of every chunk waited for a full memory round trip.)
+//   * the shared operand is read from LDS one (half, column tile) group ahead of the MFMAs that use it, instead of directly in
+//     front of them (eight exposed LDS latencies per chunk).
+// Which units the next chunk needs is a wave-uniform count (CI_NACT): inside a phase it is NA, at the phase's last chunk the
+// units that become active are requested as well.
+#define CI_NACT(x) (((x) >= pb[0]) + ((x) >= pb[1]) + ((x) >= pb[2]) + ((x) >= pb[3]))
+// buffer_load with the matrix descriptor in SGPRs, a 32-bit lane offset and a scalar (unit row + chunk) offset: no 64-bit
+// per-lane address arithmetic and no address registers held across the loop (T8 of the guide)
+#define CI_HLOAD(u, h, cc) hc[u][h] = ci_bload(rsu[u], voffh + 64 * (h), urow[u] + (cc) * (CI_KC * 8))
+// The loop body is straight-line code (the waitcnt pass counts outstanding loads exactly only without branches around
+// them): the requests for chunk c + 1 are unconditional, in the last chunk they re-read that chunk (index clamped) and
+// the result is dropped.  Units that become active at a phase boundary are requested by CI_PHASE_ENTER between the loops.
+#define CI_PHASE_ENTER(NA0, NA1, cc)                                                                               \
+    if ((cc) < nch) {                                                                                              \
+        _Pragma("unroll") for (int u = NA0; u < UPW; u++)                                                          \
+            if (u < (NA1)) { CI_HLOAD(u, 0, (cc)); CI_HLOAD(u, 1, (cc)); }                                         \
+    }
 #define CI_CHUNK_PHASE(NA, lo, hi)                                                                                 \
     for (int c = (lo); c < (hi); c++) {                                                                            \
         const int buf = c & 1;                                                                                     \
-        _Pragma("unroll") for (int hf = 0; hf < CI_KC / 16; hf++) {                                                \
-            v2d hc[NA > 0 ? NA : 1][2];                                                                            \
-            _Pragma("unroll") for (int u = 0; u < NA; u++)                                                         \
-                _Pragma("unroll") for (int h = 0; h < 2; h++)                                                      \
-                    hc[u][h] = CI_EXP_SCALE(*(const gv2d_t *)(ub[u] + CI_EXP_OFF + loff + c * CI_KC + 16 * hf + 8 * h)); \
-            if (hf == 0 && c + 1 < nch) {                                                                          \
-                _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = CI_EXP_SCALE(Bsrc[CI_EXP_OFF + (c + 1) * CI_KC + e]); \
-            }                                                                                                      \
-            if (NA > 0) {                                                                                          \
-                _Pragma("unroll") for (int h = 0; h < 2; h++) {                                                    \
-                    _Pragma("unroll") for (int ct = 0; ct < 4; ct++) {                                             \
-                        const v2d a = *(const v2d *)&sm.Bs[buf][16 * ct + li][16 * hf + 8 * h + 2 * g];           \
-                        _Pragma("unroll") for (int s = 0; s < 2; s++)                                              \
-                            _Pragma("unroll") for (int u = 0; u < NA; u++)                                         \
-                                acc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], hc[u][h][s], acc[ct][u], 0, 0, 0); \
-                    }                                                                                              \
+        const int cn = (c + 1 < nch) ? c + 1 : c;                 /* next chunk, clamped */                        \
+        _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[cn * CI_KC + e];                           \
+        if (NA > 0) {                                                                                              \
+            v2d a_cur = *(const v2d *)&sm.Bs[buf][li][2 * g];                                                      \
+            _Pragma("unroll") for (int hct = 0; hct < 8; hct++) {                                                  \
+                const int h = hct >> 2, ct = hct & 3;                                                              \
+                v2d a_nxt = a_cur;                                                                                 \
+                if (hct < 7) a_nxt = *(const v2d *)&sm.Bs[buf][16 * ((hct + 1) & 3) + li][8 * ((hct + 1) >> 2) + 2 * g]; \
+                _Pragma("unroll") for (int s = 0; s < 2; s++)                                                      \
+                    _Pragma("unroll") for (int u = 0; u < NA; u++)                                                 \
+                        acc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[s], hc[u][h][s], acc[ct][u], 0, 0, 0); \
+                a_cur = a_nxt;                                                                                     \
+                if (ct == 3) {   /* half h is consumed: request it for the next chunk */                           \
+                    _Pragma("unroll") for (int u = 0; u < NA; u++) { CI_HLOAD(u, h, cn); }                         \
                 }                                                                                                  \
             }                                                                                                      \
         }                                                                                                          \
-        /* z history product (pass 0 only): last wave, lane = panel column */                                      \
-        if (pass == 0 && wave == NW - 1) {                                                                         \
-            if (npad <= 1024) {                                                                                    \
-                _Pragma("unroll") for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * sm.zs[c * CI_KC + kk]; \
-            } else {                                                                                               \
-                _Pragma("unroll") for (int kk = 0; kk < CI_KC; kk++) zsum += sm.Bs[buf][lane][kk] * zz[c * CI_KC + kk];    \
+        /* z history product (pass 0 only): lane = panel column, every wave takes CI_KC / NW of the chunk's columns (left to */ \
+        /* one wave, its 16 + 16 operands in flight made hipcc spill two accumulator tiles inside this loop)            */ \
+        if (pass == 0) {                                                                                           \
+            _Pragma("unroll") for (int kq = 0; kq < CI_KC / NW; kq++) {                                            \
+                const int kk = (CI_KC / NW) * wave + kq;                                                           \
+                zsum += sm.Bs[buf][lane][kk] * ((npad <= 1024) ? sm.zs[c * CI_KC + kk] : (double)zz[c * CI_KC + kk]); \
             }                                                                                                      \
         }                                                                                                          \
         STAMP(4); /* MFMA block (+ z product) */                                                                   \
@@ -482,6 +512,9 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
     const int li = lane & 15, g = lane >> 4;
     const int wu = wave & 3, wg = wave >> 2;
     const int loff = li * ld + 2 * g;                      // lane part of a history-operand address
+    const int voffh = loff * 8;                            // the same in bytes (buffer_load voffset)
+    // descriptors of this patient's two matrices, built from wave-uniform values only
+    const int mat_bytes = __builtin_amdgcn_readfirstlane((int)((size_t)ld * ld * sizeof(double)));
     // row-contiguous access of a 64 x 16 column slab: one instruction = 8 rows x 128 B (whole cache lines); the 8-byte
     // accesses of the transposed accumulator layout touch 64 lines per instruction and made panel init + panel store
     // tag-lookup bound in the L1 (a fifth of the kernel).  The slab is transposed through LDS instead.
@@ -515,6 +548,8 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
             bool act[UPW], isM[UPW];
             int rowb[UPW], cf[UPW];
             const gd_t *ub[UPW];
+            int urow[UPW];   // byte offset of the unit's first row inside its matrix
+            __amdgpu_buffer_rsrc_t rsu[UPW];   // descriptor of the unit's matrix (L or U of this patient), provably wave-uniform
 #pragma unroll
             for (int u = 0; u < UPW; u++) {
                 const int bidx = pass * BPP + u * G + wg;
@@ -527,6 +562,12 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 // kernel's MFMAs)
                 cf[u] = act[u] ? (isM[u] ? 0 : (64 * rblk + 16 * wu) / CI_KC) : (1 << 30);
                 ub[u] = (isM[u] ? Lb : Ub) + (size_t)rowb[u] * ld;
+                urow[u] = __builtin_amdgcn_readfirstlane(rowb[u] * ld * 8);
+                {
+                    const unsigned long long pb64 = (unsigned long long)(isM[u] ? L.Kmat : L.Linv) + (unsigned long long)b * (unsigned long long)mat_bytes;
+                    const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)pb64), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(pb64 >> 32));
+                    rsu[u] = __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi32 << 32) | lo32), 0, mat_bytes, 0x00020000);
+                }
             }
             // first chunk anybody in the workgroup needs: slot 0 of group 0 has the longest history
             const int bidx0 = pass * BPP;
@@ -620,11 +661,17 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 int pb[5];
 #pragma unroll
                 for (int u = 0; u < 5; u++) pb[u] = (u < UPW) ? clampc(cf[u < UPW ? u : 0]) : nch;
+                static_assert(UPW <= 4 && CI_KC == 16, "the pipelined chunk loop is written for 16-column chunks and <= 4 units");
+                // history operand registers: CI_PHASE_ENTER requests a unit's first chunk, the loop every later one half a chunk ahead
+                v2d hc[UPW][2];
+#pragma unroll
+                for (int u = 0; u < UPW; u++) { hc[u][0] = (v2d){0.0, 0.0}; hc[u][1] = (v2d){0.0, 0.0}; }
                 CI_CHUNK_PHASE(0, cstart, pb[0])
+                CI_PHASE_ENTER(0, CI_NACT(pb[0]), pb[0])
                 CI_CHUNK_PHASE(1, pb[0], pb[1])
-                if constexpr (UPW >= 2) CI_CHUNK_PHASE(2, pb[1], pb[2])
-                if constexpr (UPW >= 3) CI_CHUNK_PHASE(3, pb[2], pb[3])
-                if constexpr (UPW >= 4) CI_CHUNK_PHASE(4, pb[3], pb[4])
+                if constexpr (UPW >= 2) { CI_PHASE_ENTER(1, CI_NACT(pb[1]), pb[1]) CI_CHUNK_PHASE(2, pb[1], pb[2]) }
+                if constexpr (UPW >= 3) { CI_PHASE_ENTER(2, CI_NACT(pb[2]), pb[2]) CI_CHUNK_PHASE(3, pb[2], pb[3]) }
+                if constexpr (UPW >= 4) { CI_PHASE_ENTER(3, CI_NACT(pb[3]), pb[3]) CI_CHUNK_PHASE(4, pb[3], pb[4]) }
             } else {
                 __syncthreads();   // init slabs done before Dk (same LDS) is written below
             }
@@ -637,7 +684,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                         for (int r = 0; r < 4; r++) sm.Dk[16 * wu + li][16 * ct + 4 * r + g] = -acc[ct][0][r];
                 }
-                if (wave == NW - 1) sm.zacc[lane] = zsum;
+                sm.zp.zpart[wave][lane] = zsum;
                 __syncthreads();
                 STAMP(0);   // wait for the slowest GEMM wave (folded into 0)
                 // one wave factors the block while the co-resident workgroup's waves own the SIMDs (measured at 512 x N=512, two
@@ -651,7 +698,10 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     if (!sm.fail) {
                         // z_k = L_kk^-1 (y_k - zacc).  Xk has exact zeros above the diagonal, so the fixed-length loops
                         // below add the same terms in the same order as triangular loops, but pipeline their LDS reads
-                        sm.rhs[lane] = ((c0 + lane < n) ? y[c0 + lane] : 0.0) - sm.zacc[lane];
+                        double zacc = 0.0;   // fixed order over the waves' partial products
+#pragma unroll
+                        for (int w2 = 0; w2 < NW; w2++) zacc += sm.zp.zpart[w2][lane];
+                        sm.rhs[lane] = ((c0 + lane < n) ? y[c0 + lane] : 0.0) - zacc;
                         __builtin_amdgcn_wave_barrier();
                         double s = 0.0;
 #pragma unroll 16
@@ -784,6 +834,12 @@ __global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int wa
     const int b = blockIdx.x, tid = threadIdx.x;
     if (L.status[b] < 0) return;
     if (only_small && L.pn[L.bslot[b]] > 64) return;
+#ifdef CI_EXP_STAGGER
+    // experiment: the second resident workgroup of a CU starts half a step late (anti-phase GEMM / serial phases)
+    if (NW == 4 && ((CI_EXP_STAGGER_MODE == 0 && b >= (int)gridDim.x / 2) || (CI_EXP_STAGGER_MODE == 1 && (b & 1)))) {
+        for (int it = 0; it < CI_EXP_STAGGER; it++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     // loaded values the whole workgroup agrees on: pin them to scalar registers, otherwise every quantity derived from
     // n (block counts, slot tables, row bases) lives in VGPRs across the MFMA loop and its branches run on exec masks
     const int slot = __builtin_amdgcn_readfirstlane(L.bslot[b]);
