@@ -475,9 +475,12 @@ __device__ __attribute__((noinline)) void diag_factor_wg(ld_t *D, ld_t *X, ld_t 
         /* z history product (pass 0 only): lane = panel column, every wave takes CI_KC / NW of the chunk's columns (left to */ \
         /* one wave, its 16 + 16 operands in flight made hipcc spill two accumulator tiles inside this loop)            */ \
         if (pass == 0) {                                                                                           \
-            _Pragma("unroll") for (int kq = 0; kq < CI_KC / NW; kq++) {                                            \
-                const int kk = (CI_KC / NW) * wave + kq;                                                           \
-                zsum += sm.Bs[buf][lane][kk] * ((npad <= 1024) ? sm.zs[c * CI_KC + kk] : (double)zz[c * CI_KC + kk]); \
+            if (npad <= 1024) {   /* z history in LDS: no vector-memory wait in this path */                       \
+                _Pragma("unroll") for (int kq = 0; kq < CI_KC / NW; kq++)                                          \
+                    zsum += sm.Bs[buf][lane][(CI_KC / NW) * wave + kq] * sm.zs[c * CI_KC + (CI_KC / NW) * wave + kq]; \
+            } else {                                                                                               \
+                _Pragma("unroll") for (int kq = 0; kq < CI_KC / NW; kq++)                                          \
+                    zsum += sm.Bs[buf][lane][(CI_KC / NW) * wave + kq] * zz[c * CI_KC + (CI_KC / NW) * wave + kq]; \
             }                                                                                                      \
         }                                                                                                          \
         STAMP(4); /* MFMA block (+ z product) */                                                                   \
