@@ -359,7 +359,9 @@ __device__ __forceinline__ void trail_tile(ld_t *D, int s2, int u, int t, int li
         c = __builtin_amdgcn_mfma_f64_16x16x4f64(-TD(s2, t)[li * CI_S + 4 * k + g], TD(u, t)[li * CI_S + 4 * k + g], c, 0, 0, 0);
     tile_st(TD(s2, u), c, li, g);
 }
-__device__ __attribute__((noinline)) void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t *fail, ld_t *logdet, int wave, int lane) {
+// (inlined into its callers: as an out-of-line function it claimed 248 VGPRs + 32 AGPRs for callee-saved traffic, and a kernel is
+//  allocated the maximum over its call graph -- k_la_step lost its second workgroup per CU to a callee it runs in one role)
+__device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t *fail, ld_t *logdet, int wave, int lane) {
     const int li = lane & 15, g = lane >> 4;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
     if (wave == 0) {

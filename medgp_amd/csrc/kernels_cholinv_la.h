@@ -103,14 +103,17 @@ __device__ __forceinline__ void la_gemm(const double *Hist, const double *Bpanel
 #pragma unroll
             for (int h = 0; h < 4; h++) an[h] = *(const v2d *)(Arow + (c + 1) * LA_KC + 8 * h);
         }
+        // the shared operand of the next 8-column group is read from LDS before the MFMAs of the current one
+        v2d b_cur = *(const v2d *)&sm.Bs[buf][li][2 * g];
 #pragma unroll
-        for (int h = 0; h < 4; h++)
+        for (int hct = 0; hct < 16; hct++) {
+            const int h = hct >> 2, ct = hct & 3;
+            v2d b_nxt = b_cur;
+            if (hct < 15) b_nxt = *(const v2d *)&sm.Bs[buf][16 * ((hct + 1) & 3) + li][8 * ((hct + 1) >> 2) + 2 * g];
 #pragma unroll
-            for (int ct = 0; ct < 4; ct++) {
-                const v2d bf = *(const v2d *)&sm.Bs[buf][16 * ct + li][8 * h + 2 * g];
-#pragma unroll
-                for (int s = 0; s < 2; s++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[h][s], bf[s], acc[ct], 0, 0, 0);
-            }
+            for (int s = 0; s < 2; s++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[h][s], b_cur[s], acc[ct], 0, 0, 0);
+            b_cur = b_nxt;
+        }
         if (c + 1 < nch) {
 #pragma unroll
             for (int u = 0; u < 4; u++) *(v2d *)&sm.Bs[buf ^ 1][srow][scg + 2 * u] = bst[u];
@@ -266,10 +269,11 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     v2d xreg[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) xreg[e] = *(const v2d *)(Xg + 2 * (tid + LA_THREADS * e));
-    v4d pval[4], oval[4];
+    v4d pval[4];
     if (has_next) la_load_t(A.pnx + ((size_t)b * 2 + (k & 1)) * 4096 + (size_t)(16 * w) * 64, 64, pval, li, g);
-    double *oblk = Rb + (size_t)(16 * w) * ld + c0;
-    if (!is_D) la_load_t(oblk, ld, oval, li, g);
+    double *oblk = Rb + (size_t)(16 * w) * ld + c0;   // the role's own block of panel k: read at its use (F roles are not on
+                                                      // the critical path; holding it from here cost the kernel its second
+                                                      // workgroup per CU)
     // ---- (1) pre-solve block of panel k+1: acc = -init + partials + term of panel k-1     (non-transposed tiles)
     v4d acc[4];
 #pragma unroll
@@ -311,10 +315,10 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     // ---- (4) own rows of panel k: row_r[C_k] = P_r,k X_k^T   (D: that is the block above, already in o;  U_k: the
     //      diagonal block U_kk itself, final since the previous launch)
     if (!is_D) {
-        if (row.kind == 1 && row.blk == k) {
-#pragma unroll
-            for (int ct = 0; ct < 4; ct++) o[ct] = oval[ct];
-        } else {
+        if (row.kind == 1 && row.blk == k) la_load_t(oblk, ld, o, li, g);
+        else {
+            v4d oval[4];
+            la_load_t(oblk, ld, oval, li, g);
             la_trsm(sm.Xs, oval, o, li, g);
             la_store_t(oblk, ld, o, li, g);
         }
