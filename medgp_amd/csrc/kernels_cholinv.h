@@ -592,34 +592,32 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                 for (int u = 0; u < UPW; u++) { ldu[u] = act[u] && isM[u]; anyld = anyld || ldu[u]; }
                 if (anyld) {   // branch-free inside: units without a K block read the block of slot 0 and discard it
+                    // all 64 columns are requested at once (the registers the accumulators will occupy are free here): one
+                    // memory round trip per pass instead of one per 32-column half
+                    v2d kin[4][2 * UPW];
 #pragma unroll
-                    for (int half = 0; half < 2; half++) {
-                        v2d kin[2][2 * UPW];
+                    for (int u = 0; u < UPW; u++) {
+                        const gd_t *src = (ldu[u] ? ub[u] : ub[0]) + (size_t)srow8 * ld + c0 + 2 * spc;
 #pragma unroll
-                        for (int u = 0; u < UPW; u++) {
-                            const gd_t *src = (ldu[u] ? ub[u] : ub[0]) + (size_t)srow8 * ld + c0 + 32 * half + 2 * spc;
+                        for (int ct = 0; ct < 4; ct++)
 #pragma unroll
-                            for (int cth = 0; cth < 2; cth++)
+                            for (int j = 0; j < 2; j++) kin[ct][2 * u + j] = *(const gv2d_t *)(src + (size_t)(8 * j) * ld + 16 * ct);
+                    }
 #pragma unroll
-                                for (int j = 0; j < 2; j++) kin[cth][2 * u + j] = *(const gv2d_t *)(src + (size_t)(8 * j) * ld + 16 * cth);
-                        }
+                    for (int ct = 0; ct < 4; ct++) {
 #pragma unroll
-                        for (int cth = 0; cth < 2; cth++) {
-                            const int ct = 2 * half + cth;
+                        for (int u = 0; u < UPW; u++)
 #pragma unroll
-                            for (int u = 0; u < UPW; u++)
+                            for (int j = 0; j < 2; j++) *(v2d *)&S[16 * u + 8 * j + srow8][2 * spc] = kin[ct][2 * u + j];
+                        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                                for (int j = 0; j < 2; j++) *(v2d *)&S[16 * u + 8 * j + srow8][2 * spc] = kin[cth][2 * u + j];
-                            __builtin_amdgcn_wave_barrier();
+                        for (int u = 0; u < UPW; u++)
 #pragma unroll
-                            for (int u = 0; u < UPW; u++)
-#pragma unroll
-                                for (int r = 0; r < 4; r++) {
-                                    const double kv = S[16 * u + (lane_o & 15)][4 * r + (lane_o >> 4)];
-                                    acc[ct][u][r] = ldu[u] ? -kv : 0.0;
-                                }
-                            __builtin_amdgcn_wave_barrier();
-                        }
+                            for (int r = 0; r < 4; r++) {
+                                const double kv = S[16 * u + (lane_o & 15)][4 * r + (lane_o >> 4)];
+                                acc[ct][u][r] = ldu[u] ? -kv : 0.0;
+                            }
+                        __builtin_amdgcn_wave_barrier();
                     }
                 } else {
 #pragma unroll
