@@ -256,10 +256,11 @@ def main():
     ctx = medgp_amd.Context(7, Q, D, R, device=local_rank)
     ctx.reserve(P, N, P)
     thetas = np.empty((P, H))
+    pts = []
     for s in range(P):
-        m, t, y = synth.patient(args.seed, first + s, D, N)
-        ctx.set_patient(s, m, t, y)
+        pts.append(synth.patient(args.seed, first + s, D, N))
         thetas[s] = synth.theta(args.seed, first + s, 7, Q, D, R)
+    ctx.set_patients(np.arange(P), pts)     # packed upload: one transfer for the whole shard
     if not args.no_prior:
         ctx.set_prior(-1, *synth.hier_gamma_prior(Q, D, R, 0.01))
     slots = np.arange(P, dtype=np.int32)

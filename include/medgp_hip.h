@@ -119,8 +119,12 @@ int medgp_set_prior(medgp_ctx *ctx, int slot, const uint8_t *flag, const int32_t
 int medgp_nlml_grad(medgp_ctx *ctx, int nbatch, const int32_t *slots, const double *theta, int flag_grad,
                     double *nlml, double *grad, int32_t *status);
 
-/* Same operator with theta / nlml / grad / status in DEVICE memory of ctx's device; asynchronous on
- * the context's stream (slots stays a host array: it only selects resident patients). */
+/* Same operator with theta / nlml / grad / status in DEVICE memory of ctx's device, queued on the context's stream
+ * (slots stays a host array: it only selects resident patients).  Asynchronous when every entry is factored by the
+ * one-workgroup-per-patient kernel (more than 0.6 x #CU entries, or every n <= 64).  With fewer, larger entries the
+ * multi-CU schedule is used and the call reads the per-entry factorisation status back ONCE before it returns (the
+ * reference's jitter loop, ref: inference/c_inference_exact.cpp:99-111, is driven from the host there): the results are
+ * still produced on the stream, but the call itself waits for the factorisation. */
 int medgp_nlml_grad_device(medgp_ctx *ctx, int nbatch, const int32_t *slots, const double *theta_dev,
                            int flag_grad, double *nlml_dev, double *grad_dev, int32_t *status_dev);
 
