@@ -3,6 +3,7 @@
 // point fails with MEDGP_ERR_NODEVICE.
 #include "../../include/medgp_hip.h"
 #include "medgp_dev.h"
+#include "kernels_core.h"
 #include "kernels_v0.h"
 #include "kernels_cholinv.h"
 #include "kernels_cholinv_mc.h"

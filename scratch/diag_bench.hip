@@ -3,8 +3,7 @@
 #include <cstdio>
 #include <vector>
 #include <cmath>
-#include "../medgp_amd/csrc/medgp_dev.h"
-__device__ __attribute__((noinline)) void reassemble_wg(const MedgpDev &, int, int, int, int, int) {}
+#include "../medgp_amd/csrc/kernels_core.h"
 #include "../medgp_amd/csrc/kernels_cholinv.h"
 struct Sm { double D[64][66], X[64][66]; alignas(16) double dv[64 + 128]; double logdet; int fail; };
 template <int MODE>
