@@ -134,6 +134,11 @@ __device__ inline void tile_st(ld_t *Cp, v4d c, int li, int g) {
 // ds_read_b128 pairs -- 60 LDS reads instead of 240 v_readlane per tile.  Every a[c] still receives the same FMAs in the
 // same (ascending j) order: results are bit-identical to the all-readlane form.  scr: 128 doubles of LDS owned by this wave.
 __device__ __forceinline__ bool diag16(ld_t *T, ld_t *X, ld_t *dv, ld_t *scr, int lane) {
+    // LDL^T order of operations: the column recurrence only needs the RECIPROCAL of each pivot (v_rcp_f64 + two Newton steps,
+    // 5 instructions on the serial chain) -- column j stays unscaled, the multipliers are t = a[j] / d_j; the reciprocal
+    // square roots of all 16 pivots are taken once at the end, lane-parallel, and every column is scaled by its own.
+    // (Scaling each column as it is finished put v_rsq_f64 + two coupled Goldschmidt steps + a residual correction, 12
+    //  instructions, on the chain of every column.)
     const int i = lane & 15, i5 = lane & 31;
     const bool ident = i5 >= 16;
     double a[16];
@@ -143,35 +148,26 @@ __device__ __forceinline__ bool diag16(ld_t *T, ld_t *X, ld_t *dv, ld_t *scr, in
         a[c] = ident ? ((c == i) ? 1.0 : 0.0) : t;
     }
     bool ok = true;
-    double dj = 1.0;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
+        double tm[4];   // multipliers of the panel's columns: lane c holds a[c][j] / d_j
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = 4 * p + k;
             const double piv = readlane_d(a[j], j);
             ok = ok && (piv > 0.0);
-            // sqrt and reciprocal sqrt together: v_rsq_f64 seed + two coupled Goldschmidt steps + one residual
-            // correction (about 1 ulp each; pivots of a scaled covariance never need the denormal rescaling that makes
-            // the library sqrt + divide a ~450-cycle dependent chain on this serial path)
-            const double y0 = __builtin_amdgcn_rsq(piv);
-            double gg = piv * y0, hh = 0.5 * y0;
-            double rr = fma(-gg, hh, 0.5);
-            gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
-            rr = fma(-gg, hh, 0.5);
-            gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
-            const double dd = fma(-gg, gg, piv);
-            const double sq = fma(dd, hh, gg), rinv = hh + hh;
-            dj = (i5 == j) ? sq : dj;
-            a[j] = (i5 == j) ? sq : a[j] * rinv;
+            double r = __builtin_amdgcn_rcp(piv);
+            r = fma(fma(-piv, r, 1.0), r, r);
+            r = fma(fma(-piv, r, 1.0), r, r);
+            tm[k] = a[j] * r;
 #pragma unroll
-            for (int k2 = k + 1; k2 < 4; k2++) a[4 * p + k2] -= a[j] * readlane_d(a[j], 4 * p + k2);
+            for (int k2 = k + 1; k2 < 4; k2++) a[4 * p + k2] -= a[j] * readlane_d(tm[k], 4 * p + k2);
         }
         if (p < 3) {
             ld_t *sp = scr + 64 * (p & 1);
             if (lane < 16) {
-                *(lv2d_t *)&sp[4 * lane] = (v2d){a[4 * p], a[4 * p + 1]};
-                *(lv2d_t *)&sp[4 * lane + 2] = (v2d){a[4 * p + 2], a[4 * p + 3]};
+                *(lv2d_t *)&sp[4 * lane] = (v2d){tm[0], tm[1]};
+                *(lv2d_t *)&sp[4 * lane + 2] = (v2d){tm[2], tm[3]};
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -184,8 +180,23 @@ __device__ __forceinline__ bool diag16(ld_t *T, ld_t *X, ld_t *dv, ld_t *scr, in
             }
         }
     }
+    // pivots: lane j (< 16) holds d_j in a[j]
+    double dj = 1.0;
+#pragma unroll
+    for (int c = 0; c < 16; c++) dj = (i5 == c) ? a[c] : dj;
+    // sqrt and reciprocal sqrt of all pivots at once: v_rsq_f64 seed + two coupled Goldschmidt steps + one residual correction
+    const double y0 = __builtin_amdgcn_rsq(dj);
+    double gg = dj * y0, hh = 0.5 * y0;
+    double rr = fma(-gg, hh, 0.5);
+    gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
+    rr = fma(-gg, hh, 0.5);
+    gg = fma(gg, rr, gg); hh = fma(hh, rr, hh);
+    const double dd = fma(-gg, gg, dj);
+    const double sq = fma(dd, hh, gg), rinv = hh + hh;   // sqrt(d_j), 1 / sqrt(d_j) in lane j
+#pragma unroll
+    for (int c = 0; c < 16; c++) a[c] *= readlane_d(rinv, c);
     if (lane < 16) {
-        dv[lane] = dj;
+        dv[lane] = sq;
 #pragma unroll
         for (int c = 0; c < 16; c++)
             if (c <= i) T[i * CI_S + c] = a[c];
