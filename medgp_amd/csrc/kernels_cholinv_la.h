@@ -198,8 +198,18 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
 //   M_i, i = k+2 .. nb-1   |  U_rho, rho = 0 .. k (inverse only)  |  Y
 // and for L at step k (partials of panel k+2 over history panels <= k-1; rows that exist in panel k+2 and have such history):
 //   M_i, i = k+2 .. nb-1   |  U_rho, rho = 0 .. k-1 (inverse only) |  Y       x  slice index
+#ifdef LA_STAMPS
+// diagnostic build (scratch/la_stamps.py): longest workgroup of each role per step (s_memtime ticks = shader cycles), kept in
+// the idle slab of entry 0
+#define LA_T0() const unsigned long long la_t0 = __builtin_amdgcn_s_memtime()
+#define LA_TEND(role) do { if (threadIdx.x == 0) atomicMax((unsigned long long *)L.slab + 8 * k + (role), __builtin_amdgcn_s_memtime() - la_t0); } while (0)
+#else
+#define LA_T0() do {} while (0)
+#define LA_TEND(role) do {} while (0)
+#endif
 __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A, int k, int want_mode) {
     __shared__ LaSmem sm;
+    LA_T0();
     const int b = blockIdx.x;
     if (L.status[b] < 0) return;
     const int slot = __builtin_amdgcn_readfirstlane(L.bslot[b]);
@@ -256,6 +266,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
         for (int ct = 0; ct < 4; ct++)
 #pragma unroll
             for (int r = 0; r < 4; r++) P[(ct * 4 + r) * 64] = acc[ct][r];
+        LA_TEND(2);
         return;
     }
 
@@ -323,7 +334,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
             la_store_t(oblk, ld, o, li, g);
         }
     }
-    if (!has_next) return;
+    if (!has_next) { LA_TEND(1); return; }
     __syncthreads();   // Ls complete
     // ---- (5) newest rank-64 term: acc += row_r[C_k] L[C_k+1,C_k]^T, straight from the trsm registers (A operand)
 #pragma unroll
@@ -348,6 +359,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
 #pragma unroll
                 for (int r = 0; r < 4; r++) Pn[(16 * w + 4 * r + g) * 64 + 16 * ct + li] = -acc[ct][r];
         }
+        LA_TEND(1);
         return;
     }
     // ---- (6) D: factor the next diagonal block
@@ -369,6 +381,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
         Xn[e] = sm.Ls[rr][cc];
     }
     if (tid == 0) L.scal[b * 4 + 0] += sm.logdet;   // steps are ordered launches: fixed summation order
+    LA_TEND(0);
 }
 
 // ---- epilogue of the factorisation: z, quad = z^T z, alpha = U z, status = jitter count -----------------------------------

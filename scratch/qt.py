@@ -9,7 +9,7 @@ fg = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 Q, R = 5, min(8, D)
 nu = min(P, 8)
 pts, th = synth.cohort(11, nu, D, N, Q=Q, R=R)
-ctx = medgp_amd.Context(7, Q, D, R); ctx.reserve(P, N, P)
+ctx = medgp_amd.Context(7, Q, D, R); ctx.reserve(P, N + int(os.environ.get("QT_PAD", "0")), P)
 ctx.set_patients(np.arange(P), [pts[s % nu] for s in range(P)])
 th = np.stack([th[s % nu] for s in range(P)])
 nl, g, st = ctx.nlml_grad(np.arange(P), th, bool(fg))
