@@ -203,7 +203,9 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
 // the idle slab of entry 0
 #define LA_T0() const unsigned long long la_t0 = __builtin_amdgcn_s_memtime()
 #define LA_TEND(role) do { if (threadIdx.x == 0) atomicMax((unsigned long long *)L.slab + 8 * k + (role), __builtin_amdgcn_s_memtime() - la_t0); } while (0)
+#define LA_TD(slot) do { if (is_D && threadIdx.x == 0) ((unsigned long long *)L.slab)[8 * k + (slot)] = __builtin_amdgcn_s_memtime() - la_t0; } while (0)
 #else
+#define LA_TD(slot) do {} while (0)
 #define LA_T0() do {} while (0)
 #define LA_TEND(role) do {} while (0)
 #endif
@@ -211,9 +213,9 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     __shared__ LaSmem sm;
     LA_T0();
     const int b = blockIdx.x;
-    if (L.status[b] < 0) return;
-    const int slot = __builtin_amdgcn_readfirstlane(L.bslot[b]);
-    const int n = __builtin_amdgcn_readfirstlane(L.pn[slot]);
+    const int st0 = L.status[b], n0 = L.bn[b];      // two independent loads (bslot -> pn would be a dependent chain of three)
+    if (st0 < 0) return;
+    const int n = __builtin_amdgcn_readfirstlane(n0);
     const int ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
     if (k >= nb || nb < 2) return;
     const int want_inv = want_mode & 1;
@@ -309,6 +311,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
         // panel k-1 (final since the previous launch)
         if (k >= 1 && jf <= k - 1) la_gemm(Rb, Lb + (size_t)c1 * ld, ld, k - 1, k, acc, sm, tid, w, li, g);
     }
+    LA_TD(3);
     // ---- (2) X_k -> LDS (Bs is dead: la_gemm ends with a barrier)
 #pragma unroll
     for (int e = 0; e < 8; e++) { const int idx = 2 * (tid + LA_THREADS * e); *(v2d *)&sm.Xs[idx >> 6][idx & 63] = xreg[e]; }
@@ -336,6 +339,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     }
     if (!has_next) { LA_TEND(1); return; }
     __syncthreads();   // Ls complete
+    LA_TD(4);
     // ---- (5) newest rank-64 term: acc += row_r[C_k] L[C_k+1,C_k]^T, straight from the trsm registers (A operand)
 #pragma unroll
     for (int ct = 0; ct < 4; ct++)
@@ -362,6 +366,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
         LA_TEND(1);
         return;
     }
+    LA_TD(5);
     // ---- (6) D: factor the next diagonal block
     __syncthreads();   // every wave is done reading Xs / Ls
     if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
@@ -372,6 +377,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     __syncthreads();
     diag_factor_wg((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.Ls[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, w, lane);
     __syncthreads();
+    LA_TD(6);
     if (sm.fail) { if (tid == 0) L.status[b] = -2; return; }
     double *Xn = A.xk2 + ((size_t)b * 2 + ((k + 1) & 1)) * 4096;
     for (int e = tid; e < 64 * 64; e += LA_THREADS) {

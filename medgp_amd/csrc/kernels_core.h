@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restri
         L.scal[b * 4 + 0] = 0.0;
         L.scal[b * 4 + 1] = 0.0;
         L.jit[b] = 0;
+        L.bn[b] = n;
     }
     if (theta == nullptr) return;
     if (L.kidx == 7) {

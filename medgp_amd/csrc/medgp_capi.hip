@@ -41,7 +41,7 @@ struct medgp_ctx {
     MedgpDev dev{};
     // device allocations
     std::vector<void *> allocs;
-    int *d_proff = nullptr, *d_pcoff = nullptr, *d_jit = nullptr;
+    int *d_proff = nullptr, *d_pcoff = nullptr, *d_jit = nullptr, *d_bn = nullptr;
     int *d_pn = nullptr, *d_pmeta = nullptr, *d_pseg = nullptr, *d_bslot = nullptr, *d_status = nullptr;
     double *d_pt = nullptr, *d_py = nullptr;
     MedgpPrior *d_prior = nullptr;
@@ -391,7 +391,7 @@ MedgpDev shifted_view(const MedgpDev &L, int b0) {
     V.cs = L.cs + (size_t)b0 * Q * ld; V.sn = L.sn + (size_t)b0 * Q * ld;
     V.Kmat = L.Kmat + (size_t)b0 * ld * ld; V.Linv = L.Linv + (size_t)b0 * ld * ld;
     V.z = L.z + (size_t)b0 * ld; V.alpha = L.alpha + (size_t)b0 * ld; V.wdiag = L.wdiag + (size_t)b0 * ld;
-    V.scal = L.scal + (size_t)b0 * 4; V.status = L.status + b0; V.jit = L.jit + b0; V.xk = L.xk + (size_t)b0 * 64 * 64;
+    V.scal = L.scal + (size_t)b0 * 4; V.status = L.status + b0; V.jit = L.jit + b0; V.bn = L.bn + b0; V.xk = L.xk + (size_t)b0 * 64 * 64;
     V.S = L.S + (size_t)b0 * Q * D * D; V.SM = L.SM + (size_t)b0 * Q * D * D; V.SV = L.SV + (size_t)b0 * Q * D * D;
     V.slab = L.slab + (size_t)b0 * L.slab_stride;
     return V;
@@ -545,6 +545,7 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     if ((rc = dalloc(c, &c->d_bslot, B))) return rc;
     if ((rc = dalloc(c, &c->d_status, B))) return rc;
     if ((rc = dalloc(c, &c->d_jit, B))) return rc;
+    if ((rc = dalloc(c, &c->d_bn, B))) return rc;
     if ((rc = dalloc(c, &c->d_theta, B * H))) return rc;
     if ((rc = dalloc(c, &c->d_nlml, B))) return rc;
     if ((rc = dalloc(c, &c->d_grad, B * H))) return rc;
@@ -563,7 +564,7 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     if ((rc = dalloc(c, &wdiag, B * ldn))) return rc;
     double *xk;
     if ((rc = dalloc(c, &xk, B * 64 * 64))) return rc;
-    L.xk = xk; L.jit = c->d_jit;
+    L.xk = xk; L.jit = c->d_jit; L.bn = c->d_bn;
     if ((rc = dalloc(c, &hyp, B * L.hyp_stride))) return rc;
     if ((rc = dalloc(c, &cs, B * Q * ldn))) return rc;
     if ((rc = dalloc(c, &sn, B * Q * ldn))) return rc;

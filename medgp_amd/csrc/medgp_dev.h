@@ -47,6 +47,7 @@ struct MedgpDev {
     double *z, *alpha;       // [batch][ldn]
     double *scal;            // [batch][4]: logdet, quad, -, -
     int *status;             // [batch]
+    int *bn;                 // [batch] n of the entry's patient, written by k_prep (one load instead of the bslot -> pn chain)
     int *jit;                // [batch] jitter rounds applied so far (extra noise additions in the assembly)
     double *xk;              // [batch][64*64] L_kk^-1 of the current panel (multi-CU factorisation)
     double *S, *SM, *SV;     // [batch][Q*D*D]
