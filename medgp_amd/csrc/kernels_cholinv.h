@@ -706,7 +706,9 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 // register traffic around the out-of-line call in all four waves cost more than its shorter critical path
                 // gains; one workgroup per CU: no difference).  The look-ahead multi-CU schedule, whose diagonal chain IS the
                 // critical path, uses diag_factor_wg.
+#ifndef CI_EXP_NOFACTOR   // diagnostic build: factor skipped (results meaningless), prices the factor phase
                 if (wave == 0) diag_factor_wave((ld_t *)&sm.Dk[0][0], (ld_t *)&sm.Xk[0][0], (ld_t *)sm.rhs, (li_t *)&sm.fail, (ld_t *)&sm.logdet, lane);
+#endif
                 if (wave == 0) {
                     STAMP(3);   // diagonal factor
                     if (!sm.fail) {
