@@ -99,14 +99,23 @@ __global__ void __launch_bounds__(256) k_assemble_t(MedgpDev L) {
     // tile (the per-element gathers kept the texture-address unit as busy as the VALU).
     double bq[QT];
     int mcur = -1;
-    // row constants of the wave's 16 rows: loaded once, lane r holds row r (lanes >= 16 mirror), broadcast per row with
-    // v_readlane -- instead of 2 + 2Q dependent scalar loads (and their lgkmcnt(0) stall) in every row iteration
+    // row constants of the wave's 16 rows: loaded once, lane r holds row r (lanes >= 16 mirror) -- instead of 2 + 2Q
+    // dependent scalar loads (and their lgkmcnt(0) stall) in every row iteration
     const int irow = 64 * I + 16 * w + (lane & 15);
     const double r_t = t[irow];
     const int r_m = meta[irow];
     double r_cs[QT], r_sn[QT];
 #pragma unroll
     for (int q = 0; q < QT; q++) { r_cs[q] = csb[q * ld + irow]; r_sn[q] = snb[q * ld + irow]; }
+    // ... and handed to the row loop through LDS: a same-address read is a broadcast on the LDS pipe, where v_readlane
+    // pairs cost 2 + 4Q VALU per row in a VALU-bound loop
+    __shared__ __attribute__((aligned(16))) double rowc[4][16][2 + 2 * QT];
+    if (lane < 16) {
+        rowc[w][lane][0] = r_t;
+#pragma unroll
+        for (int q = 0; q < QT; q++) { rowc[w][lane][2 + 2 * q] = r_cs[q]; rowc[w][lane][3 + 2 * q] = r_sn[q]; }
+    }
+    __builtin_amdgcn_wave_barrier();
     for (int rr = 0; rr < 16; rr++) {
         const int i = 64 * I + 16 * w + rr;          // wave-uniform
         double v;
@@ -118,11 +127,12 @@ __global__ void __launch_bounds__(256) k_assemble_t(MedgpDev L) {
 #pragma unroll
                 for (int q = 0; q < QT; q++) bq[q] = Brow[q * D * D];
             }
-            const double dt = lane_bcast(r_t, rr) - tj, dd = dt * dt;
+            const double dt = rowc[w][rr][0] - tj, dd = dt * dt;
             double acc = 0.0;
 #pragma unroll
             for (int q = 0; q < QT; q++) {
-                const double cd = lane_bcast(r_cs[q], rr) * csj[q] + lane_bcast(r_sn[q], rr) * snj[q];
+                const v2d csn = *(const v2d *)&rowc[w][rr][2 + 2 * q];
+                const double cd = csn[0] * csj[q] + csn[1] * snj[q];
                 acc += bq[q] * (cd * exp2_nonpos(cq2n[q] * dd));
             }
             if (i == j) { const double lik = hyp[mj]; acc += lik; for (int r = 0; r < L.jit[b]; r++) acc += lik; }   // ref c_inference_exact.cpp:88-92, :101-104
