@@ -48,7 +48,7 @@ __device__ __forceinline__ v2d ci_bload(__amdgpu_buffer_rsrc_t rs, int voff, int
     do {                                                                                           \
         unsigned long long t_;                                                                     \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
-        st_acc[idx] += t_ - st_last;                                                               \
+        if (lane == 0) sm.stamps[tid >> 6][idx] += t_ - st_last;   /* LDS, not SGPRs: 16 more live SGPRs broke the build */ \
         st_last = t_;                                                                              \
     } while (0)
 #else
@@ -84,6 +84,9 @@ struct CholInvSmem {
     double red[16];
     double logdet;
     int fail;
+#ifdef MEDGP_STAMPS
+    unsigned long long stamps[NW][8];
+#endif
 };
 static_assert(sizeof(CholInvSmem<4, 4>) <= 80 * 1024, "two 4-wave workgroups per CU need <= 80 KB each");
 
@@ -207,7 +210,10 @@ __device__ __forceinline__ bool diag16(ld_t *T, ld_t *X, ld_t *dv, ld_t *scr, in
     return ok;
 }
 
-#ifdef MEDGP_STAMPS
+#if defined(MEDGP_STAMPS) && !defined(MEDGP_NO_DSTAMPS)
+#define MEDGP_DSTAMPS
+#endif
+#ifdef MEDGP_DSTAMPS
 __device__ unsigned long long g_diag_dbg[8];
 #define DSTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (lane == 0) atomicAdd(&g_diag_dbg[k], t_ - dlast); dlast = t_; } while (0)
 #else
@@ -227,7 +233,7 @@ __device__ __forceinline__ void diag_factor_wave_body(ld_t *D, ld_t *X, ld_t *dv
 #define TD(s, t) (D + (16 * (s)) * CI_S + 16 * (t))
 #define TX(s, t) (X + (16 * (s)) * CI_S + 16 * (t))
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
-#ifdef MEDGP_STAMPS
+#ifdef MEDGP_DSTAMPS
     unsigned long long dlast;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dlast)::"memory");
 #endif
@@ -330,7 +336,7 @@ __device__ __forceinline__ void diag_factor_wave_body(ld_t *D, ld_t *X, ld_t *dv
     for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
     if (lane == 0) *logdet += lg;
     DSTAMP(4);
-#ifdef MEDGP_STAMPS
+#ifdef MEDGP_DSTAMPS
     if (lane == 0) atomicAdd(&g_diag_dbg[7], 1ull);
 #endif
 #undef TD
@@ -549,7 +555,8 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
     if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
     __syncthreads();
 #ifdef MEDGP_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    unsigned long long st_last;
+    if (lane < 8) sm.stamps[tid >> 6][lane] = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
 
@@ -833,7 +840,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #ifdef MEDGP_STAMPS
     if (lane == 0 && b < 64) {
         unsigned long long *dbg = (unsigned long long *)(L.slab + (size_t)b * L.slab_stride);
-        for (int e = 0; e < 8; e++) dbg[(tid >> 6) * 8 + e] = st_acc[e];
+        for (int e = 0; e < 8; e++) dbg[(tid >> 6) * 8 + e] = sm.stamps[tid >> 6][e];
     }
 #endif
     return true;

@@ -937,7 +937,7 @@ int medgp_fit_predict_batch(medgp_ctx *c, int nbatch, const int32_t *slots, cons
 
 #ifdef MEDGP_STAMPS
 // diagnostic build only: read (and clear) the phase counters of diag_factor_wave
-#ifdef MEDGP_STAMPS
+#ifdef MEDGP_DSTAMPS
 extern "C" int medgp_debug_read_diag(unsigned long long *out) {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_dbg), sizeof(z)) != hipSuccess) return -1;

@@ -7,15 +7,16 @@ capi.lib_path = lambda: '/root/repo/scratch/libmedgp_hip_stamps.so'
 D,N,Q,R=24,512,5,8
 names=['init+wait','inithalf0','zsolve|diagwait','diagfac+st','mfma','trsm+end','stagest','chunkbar']
 for P in (int(os.environ.get("SP","512")),):
-    pts, th = synth.cohort(11, min(P,16), D, N, Q=Q, R=R)
-    ctx = medgp_amd.Context(7, Q, D, R); ctx.reserve(P, N, P)
-    for s in range(P): ctx.set_patient(s, *pts[s % len(pts)])
-    th = np.stack([th[s % len(pts)] for s in range(P)])
+    pts = [synth.patient(2024, s, D, N) for s in range(P)]
+    th = np.stack([synth.theta(2024, s, 7, Q, D, R) for s in range(P)])
+    ctx = medgp_amd.Context(7, Q, D, R); ctx.reserve(P, N, P); ctx.set_patients(np.arange(P), pts)
     slots=np.arange(P,dtype=np.int32); nl=np.empty(P); g=np.empty((P,ctx.H)); st=np.empty(P,np.int32)
     lib=capi.load()
     for it in range(2):
+        st[:] = 99
         lib.medgp_nlml_grad(ctx._h, P, slots.ctypes.data_as(C.POINTER(C.c_int32)), th.ctypes.data_as(C.POINTER(C.c_double)), 1, nl.ctypes.data_as(C.POINTER(C.c_double)), g.ctypes.data_as(C.POINTER(C.c_double)), st.ctypes.data_as(C.POINTER(C.c_int32)))
     nw = 4
+    print('status', np.unique(st, return_counts=True))
     for b in (0, 1, min(P-1, 40)):
         buf=np.zeros(nw*8, np.uint64)
         lib.medgp_debug_read_slab.argtypes=[C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -29,10 +30,9 @@ for P in (int(os.environ.get("SP","512")),):
 # wall time of the stamped build's kernel (HIP events) for comparison with the production build
 import time
 P=512
-pts, th = synth.cohort(11, 16, D, N, Q=Q, R=R)
-ctx = medgp_amd.Context(7, Q, D, R); ctx.reserve(P, N, P)
-for s in range(P): ctx.set_patient(s, *pts[s % 16])
-th = np.stack([th[s % 16] for s in range(P)])
+pts = [synth.patient(2024, s, D, N) for s in range(P)]
+th = np.stack([synth.theta(2024, s, 7, Q, D, R) for s in range(P)])
+ctx = medgp_amd.Context(7, Q, D, R); ctx.reserve(P, N, P); ctx.set_patients(np.arange(P), pts)
 os.environ.pop('MEDGP_DBG_NOWGRAD', None)
 ctx.nlml_grad(np.arange(P), th, True)
 ctx.profile_enable(True)
