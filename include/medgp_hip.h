@@ -162,6 +162,17 @@ int medgp_factor(medgp_ctx *ctx, int slot, const double *theta, double *L, doubl
 int medgp_fit_predict_batch(medgp_ctx *ctx, int nbatch, const int32_t *slots, const double *theta,
                             const int32_t *meta2, const float *t2, float *mean, float *var, int32_t *status);
 
+/* Cohort statistics, the step after training: for each of nseries independent sample series
+ * (series s = data[off[s] .. off[s] + cnt[s])) the Gaussian kernel density estimate with Silverman's bandwidth evaluated AT the
+ * samples, and its "mode": weighted != 0: sum x dens / sum dens; weighted == 0: the sample with the largest density (first one).
+ * Replaces compute_kde + compute_mode, ref: medgpc/clustering/mode_estimate.py:438-450 (statsmodels KDEUnivariate, kernel "gau",
+ * bw "silverman"), as called per nugget / per cluster mu, v / per element of the aggregated B matrices by
+ * output_mode_LMC_SM (ref: :277-279, :339-351, :410-413).  One-shot call on `device`, host arrays in and out, no context.
+ * status[s]: 0 ok, -1 when the reference's fit would raise (n < 2, non-finite sample, zero bandwidth); mode[s] is NaN then.
+ * bw (the bandwidths) and kernel_ms (HIP-event time of the kernel) may be NULL.  Errors: medgp_last_error(NULL). */
+int medgp_kde_mode(int device, int nseries, const int64_t *off, const int32_t *cnt, const double *data, int weighted,
+                   double *mode, double *bw, int32_t *status, double *kernel_ms);
+
 /* block until all work queued on the context's stream is complete */
 int medgp_synchronize(medgp_ctx *ctx);
 

@@ -11,6 +11,7 @@
 #include "kernels_assemble.h"
 #include "kernels_wgrad.h"
 #include "kernels_io.h"
+#include "kernels_cohort.h"
 
 #include <algorithm>
 #include <cmath>
@@ -982,6 +983,48 @@ int medgp_profile_reset(medgp_ctx *c) {
     if (rc) return rc;
     for (int k = 0; k < KID_COUNT; k++) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
     return MEDGP_OK;
+}
+
+// ---- cohort statistics (no context: a one-shot call on `device`) ----------------------------------------------------------
+int medgp_kde_mode(int device, int nseries, const int64_t *off, const int32_t *cnt, const double *data, int weighted,
+                   double *mode, double *bw, int32_t *status, double *kernel_ms) {
+    medgp_ctx *none = nullptr;
+    if (nseries < 0 || (nseries > 0 && (!off || !cnt || !data || !mode || !status))) return fail(none, MEDGP_ERR_ARG, "medgp_kde_mode: bad argument");
+    if (nseries == 0) return MEDGP_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(none, MEDGP_ERR_NODEVICE, "medgp_kde_mode: no GPU (there is no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(none, MEDGP_ERR_ARG, "medgp_kde_mode: device %d of %d", device, ndev);
+    int64_t total = 0;
+    for (int s = 0; s < nseries; s++) {
+        if (cnt[s] < 0 || off[s] < 0) return fail(none, MEDGP_ERR_ARG, "medgp_kde_mode: series %d has a negative size / offset", s);
+        if (off[s] + cnt[s] > total) total = off[s] + cnt[s];
+    }
+    HIPCHK(none, hipSetDevice(device));
+    long long *d_off = nullptr; int *d_cnt = nullptr, *d_st = nullptr; double *d_x = nullptr, *d_mode = nullptr, *d_bw = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = MEDGP_OK;
+    auto chk = [&](hipError_t e, const char *what) { if (e != hipSuccess && rc == MEDGP_OK) rc = fail(none, MEDGP_ERR_HIP, "medgp_kde_mode: %s failed: %s", what, hipGetErrorString(e)); return e == hipSuccess; };
+    static_assert(sizeof(long long) == sizeof(int64_t), "offsets are passed through as 64-bit");
+    if (chk(hipMalloc(&d_off, sizeof(long long) * nseries), "hipMalloc") && chk(hipMalloc(&d_cnt, sizeof(int) * nseries), "hipMalloc") &&
+        chk(hipMalloc(&d_st, sizeof(int) * nseries), "hipMalloc") && chk(hipMalloc(&d_x, sizeof(double) * (total > 0 ? total : 1)), "hipMalloc") &&
+        chk(hipMalloc(&d_mode, sizeof(double) * nseries), "hipMalloc") && chk(hipMalloc(&d_bw, sizeof(double) * nseries), "hipMalloc") &&
+        chk(hipEventCreate(&e0), "hipEventCreate") && chk(hipEventCreate(&e1), "hipEventCreate") &&
+        chk(hipMemcpy(d_off, off, sizeof(long long) * nseries, hipMemcpyHostToDevice), "hipMemcpy") &&
+        chk(hipMemcpy(d_cnt, cnt, sizeof(int) * nseries, hipMemcpyHostToDevice), "hipMemcpy") &&
+        chk(hipMemcpy(d_x, data, sizeof(double) * total, hipMemcpyHostToDevice), "hipMemcpy")) {
+        chk(hipEventRecord(e0, nullptr), "hipEventRecord");
+        hipLaunchKernelGGL(k_kde_mode, dim3(nseries), dim3(KDE_THREADS), 0, nullptr, nseries, d_off, d_cnt, d_x, weighted ? 1 : 0, d_mode, d_bw, d_st);
+        chk(hipGetLastError(), "k_kde_mode launch");
+        chk(hipEventRecord(e1, nullptr), "hipEventRecord");
+        chk(hipMemcpy(mode, d_mode, sizeof(double) * nseries, hipMemcpyDeviceToHost), "hipMemcpy");
+        chk(hipMemcpy(status, d_st, sizeof(int) * nseries, hipMemcpyDeviceToHost), "hipMemcpy");
+        if (bw) chk(hipMemcpy(bw, d_bw, sizeof(double) * nseries, hipMemcpyDeviceToHost), "hipMemcpy");
+        if (kernel_ms && rc == MEDGP_OK) { float ms = 0.f; chk(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime"); *kernel_ms = ms; }
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    hipFree(d_off); hipFree(d_cnt); hipFree(d_st); hipFree(d_x); hipFree(d_mode); hipFree(d_bw);
+    return rc;
 }
 
 }  // extern "C"

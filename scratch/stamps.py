@@ -25,11 +25,11 @@ for P in (int(os.environ.get("SP","512")),):
         tot=a.sum(axis=1)
         print(f"P={P} b={b}: total cycles/wave {tot.mean():.0f} ({tot.mean()/2.4e3:.0f} us at 2.4GHz... memtime ticks)")
         for w in range(nw):
-            print('   wave',w,' '.join(f"{names[e]}={100*a[w,e]/tot[w]:.0f}%" for e in range(8)))
+            print('   wave',w,' '.join(f"{names[e]}={100*a[w,e]/tot[w]:.0f}%/{a[w,e]/1e3:.0f}k" for e in range(8)))
     ctx.close()
 # wall time of the stamped build's kernel (HIP events) for comparison with the production build
 import time
-P=512
+P=int(os.environ.get('SP','512'))
 pts = [synth.patient(2024, s, D, N) for s in range(P)]
 th = np.stack([synth.theta(2024, s, 7, Q, D, R) for s in range(P)])
 ctx = medgp_amd.Context(7, Q, D, R); ctx.reserve(P, N, P); ctx.set_patients(np.arange(P), pts)
