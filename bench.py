@@ -208,6 +208,19 @@ def other_configs(dev_index, seed, reps=5):
         out[name] = {"patients": P, "N": N, "D": D, "Q": Q, "R": R, "H": H, "ms_per_call": 1e3 * dt, "evals_per_s": P / dt,
                      "frac_fp64_peak": f_alg * P / dt / 1e12 / FP64_PEAK_TFLOPS, "kernel_ms": prof}
         ctx.close()
+    # cohort mode estimation: the KDE modes of one cluster of a 4096-subject cohort at D = 24
+    # (24 nuggets + mu + v + 300 elements of B; one exp per sample pair -- VALU bound)
+    from medgp_amd import capi
+    rng = np.random.default_rng(seed)
+    Pc, ns = 4096, 24 + 2 + 300
+    series = [rng.normal(size=Pc) * rng.uniform(0.1, 3.0) for _ in range(ns)]
+    capi.kde_mode(series[:8], True, dev_index)
+    t0 = time.perf_counter()
+    _, _, st, kms = capi.kde_mode(series, True, dev_index, full=True)
+    dt = time.perf_counter() - t0
+    assert np.all(st == 0)
+    out["cohort_mode_kde_P4096_D24_one_cluster"] = {"series": ns, "samples_per_series": Pc, "kernel_ms": kms, "call_ms": 1e3 * dt,
+                                                     "gaussian_pair_terms_per_s": ns * Pc * Pc / (kms * 1e-3)}
     return out
 
 

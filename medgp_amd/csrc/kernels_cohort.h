@@ -9,10 +9,16 @@
 //     A  = min(std(x, ddof=1), IQR / 1.349)  if IQR > 0 else std      IQR = scoreatpercentile(x, 75) - scoreatpercentile(x, 25)
 //     h  = 0.9 A n^(-1/5)                                             (scipy scoreatpercentile: linear interpolation at q (n-1))
 //     dens(x) = 1/h * mean_j phi((x_j - x) / h),  phi(u) = 0.3989422804014327 exp(-u^2 / 2)
-// One series = one workgroup of 256 threads.  The O(n^2) pair loop does double duty: it counts the rank of every sample
-// (the two percentiles are order statistics -- no sort) in a first sweep and sums the Gaussian terms in a second; the
-// samples of a series are staged through LDS in tiles.  All sums run in a fixed order (thread-strided partials, then a tree):
-// results are bitwise reproducible.  VALU-bound: one fp64 exp per pair.
+// Four launches, so that a handful of long series still fills 256 CUs (one workgroup per series left 326 series of 4096
+// samples at 23 % of the VALU roofline: 1.3 waves of workgroups, one wave per SIMD):
+//   k_kde_stats  (series)            mean, std (ddof 1), finiteness
+//   k_kde_rank   (series x chunks)   rank of each of the chunk's 256 samples among all n (the two percentiles are order
+//                                    statistics -- no sort); the four samples with the wanted ranks are written out
+//   k_kde_dens   (series x chunks)   bandwidth from the statistics; density at the chunk's 256 samples (thread = sample,
+//                                    all n samples staged through LDS in tiles, one fp64 exp per pair -- VALU bound);
+//                                    per-chunk partial sums of x dens and dens (and the chunk's arg max)
+//   k_kde_final  (series)            the chunks' partials added in chunk order
+// All sums run in a fixed order: results are bitwise reproducible.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels_assemble.h"   // exp2_nonpos
@@ -33,107 +39,135 @@ __device__ inline double kde_wg_sum(double v, double *red, int tid) {
     return s;
 }
 
-// status: 0 ok; -1 not finite / n < 2 / zero bandwidth (the reference's KDEUnivariate.fit raises there and
-// output_mode_kernel exits, ref: mode_estimate.py:23-26)
-__global__ void __launch_bounds__(KDE_THREADS) k_kde_mode(int nseries, const long long *off, const int *cnt, const double *data,
-                                                          int weighted, double *mode, double *bw, int *status) {
-    __shared__ double tile[KDE_TILE];
+// per-series scratch: st[0] mean, [1] std, [2] bad count, [3..6] order statistics lo25 hi25 lo75 hi75, [7] bandwidth
+#define KDE_NSTAT 8
+
+__global__ void __launch_bounds__(KDE_THREADS) k_kde_stats(int nseries, const long long *off, const int *cnt, const double *data, double *stats) {
     __shared__ double red[KDE_THREADS / 64];
-    __shared__ double ostat[4];    // order statistics lo25, hi25, lo75, hi75
-    __shared__ double bestd[KDE_THREADS];
-    __shared__ int besti[KDE_THREADS];
     const int s = blockIdx.x, tid = threadIdx.x;
-    if (s >= nseries) return;
     const int n = cnt[s];
     const double *x = data + off[s];
-    if (n < 2) { if (tid == 0) { mode[s] = nan(""); if (bw) bw[s] = nan(""); status[s] = -1; } return; }
-
-    // ---- mean, std (ddof = 1), finiteness
     double p = 0.0, bad = 0.0;
     for (int i = tid; i < n; i += KDE_THREADS) { const double v = x[i]; p += v; if (!(fabs(v) <= 1.79769313486231570815e308)) bad += 1.0; }
-    const double mean = kde_wg_sum(p, red, tid) / n;
+    const double mean = (n > 0) ? kde_wg_sum(p, red, tid) / n : 0.0;
     const double nbad = kde_wg_sum(bad, red, tid);
     p = 0.0;
     for (int i = tid; i < n; i += KDE_THREADS) { const double d = x[i] - mean; p += d * d; }
-    const double sd = sqrt(kde_wg_sum(p, red, tid) / (n - 1));
-    if (nbad > 0.0) { if (tid == 0) { mode[s] = nan(""); if (bw) bw[s] = nan(""); status[s] = -1; } return; }
+    const double ss = kde_wg_sum(p, red, tid);
+    if (tid == 0) {
+        double *st = stats + (size_t)s * KDE_NSTAT;
+        st[0] = mean; st[1] = (n > 1) ? sqrt(ss / (n - 1)) : 0.0; st[2] = nbad + (n < 2 ? 1.0 : 0.0);
+    }
+}
 
-    // ---- percentiles 25 / 75 by rank counting.  q (n-1) = k + f: value = x_(k) + f (x_(k+1) - x_(k))
+// q (n-1) = k + f: percentile = x_(k) + f (x_(k+1) - x_(k))
+__device__ inline void kde_quartile_ranks(int n, int &k25, int &k25h, int &k75, int &k75h, double &f25, double &f75) {
     const double q25 = 0.25 * (n - 1), q75 = 0.75 * (n - 1);
-    const int k25 = (int)floor(q25), k75 = (int)floor(q75);
-    const int k25h = min(k25 + 1, n - 1), k75h = min(k75 + 1, n - 1);
-    for (int i0 = 0; i0 < n; i0 += KDE_THREADS) {
-        const int i = i0 + tid;
-        const double xi = (i < n) ? x[i] : 0.0;
-        int rank = 0;
-        for (int j0 = 0; j0 < n; j0 += KDE_TILE) {
-            const int m = min(KDE_TILE, n - j0);
-            __syncthreads();
-            for (int j = tid; j < m; j += KDE_THREADS) tile[j] = x[j0 + j];
-            __syncthreads();
-            if (i < n) {
-                for (int j = 0; j < m; j++) {
-                    const double xj = tile[j];
-                    rank += (xj < xi) || (xj == xi && (j0 + j) < i);   // ties ordered by index: ranks are a permutation
-                }
+    k25 = (int)floor(q25); k75 = (int)floor(q75);
+    k25h = min(k25 + 1, n - 1); k75h = min(k75 + 1, n - 1);
+    f25 = q25 - k25; f75 = q75 - k75;
+}
+
+__global__ void __launch_bounds__(KDE_THREADS) k_kde_rank(const long long *off, const int *cnt, const double *data, double *stats) {
+    __shared__ double tile[KDE_TILE];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int n = cnt[s], i = blockIdx.y * KDE_THREADS + tid;
+    if (blockIdx.y * KDE_THREADS >= n) return;
+    double *st = stats + (size_t)s * KDE_NSTAT;
+    if (st[2] > 0.0) return;
+    const double *x = data + off[s];
+    const double xi = (i < n) ? x[i] : 0.0;
+    int rank = 0;
+    for (int j0 = 0; j0 < n; j0 += KDE_TILE) {
+        const int m = min(KDE_TILE, n - j0);
+        __syncthreads();
+        for (int j = tid; j < m; j += KDE_THREADS) tile[j] = x[j0 + j];
+        __syncthreads();
+        if (i < n) {
+#pragma unroll 8
+            for (int j = 0; j < m; j++) {
+                const double xj = tile[j];
+                rank += (xj < xi) || (xj == xi && (j0 + j) < i);   // ties ordered by index: the ranks are a permutation
             }
         }
-        if (i < n) {
-            if (rank == k25) ostat[0] = xi;
-            if (rank == k25h) ostat[1] = xi;
-            if (rank == k75) ostat[2] = xi;
-            if (rank == k75h) ostat[3] = xi;
-        }
     }
-    __syncthreads();
-    const double p25 = ostat[0] + (q25 - k25) * (ostat[1] - ostat[0]);
-    const double p75 = ostat[2] + (q75 - k75) * (ostat[3] - ostat[2]);
-    const double iqr = (p75 - p25) / 1.349;
+    if (i < n) {
+        int k25, k25h, k75, k75h; double f25, f75;
+        kde_quartile_ranks(n, k25, k25h, k75, k75h, f25, f75);
+        if (rank == k25) st[3] = xi;
+        if (rank == k25h) st[4] = xi;
+        if (rank == k75) st[5] = xi;
+        if (rank == k75h) st[6] = xi;
+    }
+}
+
+// part[(s * maxchunks + chunk) * 4 + {0: sum x dens, 1: sum dens, 2: best dens, 3: best index}]
+__global__ void __launch_bounds__(KDE_THREADS) k_kde_dens(const long long *off, const int *cnt, const double *data, double *stats,
+                                                          double *part, int maxchunks) {
+    __shared__ double tile[KDE_TILE];
+    __shared__ double red[KDE_THREADS / 64];
+    __shared__ double bestd[KDE_THREADS];
+    __shared__ int besti[KDE_THREADS];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int n = cnt[s], i = blockIdx.y * KDE_THREADS + tid;
+    if (blockIdx.y * KDE_THREADS >= n) return;
+    double *st = stats + (size_t)s * KDE_NSTAT;
+    if (st[2] > 0.0) return;
+    int k25, k25h, k75, k75h; double f25, f75;
+    kde_quartile_ranks(n, k25, k25h, k75, k75h, f25, f75);
+    const double p25 = st[3] + f25 * (st[4] - st[3]), p75 = st[5] + f75 * (st[6] - st[5]);
+    const double iqr = (p75 - p25) / 1.349, sd = st[1];
     const double A = (iqr > 0.0) ? fmin(sd, iqr) : sd;
     const double h = 0.9 * A * pow((double)n, -0.2);
-    if (bw && tid == 0) bw[s] = h;
-    if (!(h > 0.0)) { if (tid == 0) { mode[s] = nan(""); status[s] = -1; } return; }
-
-    // ---- density at every sample and the weighted mean / arg max
+    if (blockIdx.y == 0 && tid == 0) st[7] = h;
+    if (!(h > 0.0)) return;
+    const double *x = data + off[s];
     const double c2 = -0.5 * MEDGP_LOG2E / (h * h);            // exp(-u^2/2) = 2^(c2 (xj - xi)^2)
     const double norm = 0.3989422804014327 / (h * (double)n);
-    double sxd = 0.0, sdn = 0.0, bd = -1.0;
-    int bi = 0x7fffffff;
-    for (int i0 = 0; i0 < n; i0 += KDE_THREADS) {
-        const int i = i0 + tid;
-        const double xi = (i < n) ? x[i] : 0.0;
-        double acc = 0.0;
-        for (int j0 = 0; j0 < n; j0 += KDE_TILE) {
-            const int m = min(KDE_TILE, n - j0);
-            __syncthreads();
-            for (int j = tid; j < m; j += KDE_THREADS) tile[j] = x[j0 + j];
-            __syncthreads();
-            if (i < n) {
-#pragma unroll 4
-                for (int j = 0; j < m; j++) {
-                    const double d = tile[j] - xi;
-                    acc += exp2_nonpos(c2 * (d * d));
-                }
-            }
-        }
-        if (i < n) {
-            const double dens = acc * norm;
-            sxd += xi * dens;
-            sdn += dens;
-            if (dens > bd) { bd = dens; bi = i; }   // i ascends per thread: the first maximum is kept
-        }
-    }
-    if (weighted) {
-        const double a = kde_wg_sum(sxd, red, tid), b = kde_wg_sum(sdn, red, tid);
-        if (tid == 0) { mode[s] = a / b; status[s] = 0; }
-    } else {
-        bestd[tid] = bd; besti[tid] = bi;
+    const double xi = (i < n) ? x[i] : 0.0;
+    double acc = 0.0;
+    for (int j0 = 0; j0 < n; j0 += KDE_TILE) {
+        const int m = min(KDE_TILE, n - j0);
         __syncthreads();
-        if (tid == 0) {   // np.argmax: first index of the maximum
-            double md = -1.0; int mi = 0x7fffffff;
-            for (int t = 0; t < KDE_THREADS; t++)
-                if (bestd[t] > md || (bestd[t] == md && besti[t] < mi)) { md = bestd[t]; mi = besti[t]; }
-            mode[s] = x[mi]; status[s] = 0;
+        for (int j = tid; j < m; j += KDE_THREADS) tile[j] = x[j0 + j];
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < m; j++) {
+            const double d = tile[j] - xi;
+            acc += exp2_nonpos(c2 * (d * d));
         }
     }
+    const double dens = (i < n) ? acc * norm : 0.0;
+    const double a = kde_wg_sum(xi * dens, red, tid), b = kde_wg_sum(dens, red, tid);
+    bestd[tid] = (i < n) ? dens : -1.0; besti[tid] = i;
+    __syncthreads();
+    if (tid == 0) {
+        double md = -1.0; int mi = 0;
+        for (int t = 0; t < KDE_THREADS; t++) if (bestd[t] > md) { md = bestd[t]; mi = besti[t]; }   // first maximum
+        double *o = part + ((size_t)s * maxchunks + blockIdx.y) * 4;
+        o[0] = a; o[1] = b; o[2] = md; o[3] = (double)mi;
+    }
+}
+
+// status: 0 ok; -1 not finite / n < 2 / zero bandwidth (the reference's KDEUnivariate.fit raises there and
+// output_mode_kernel exits, ref: mode_estimate.py:23-26)
+__global__ void k_kde_final(int nseries, const long long *off, const int *cnt, const double *data, const double *stats, const double *part,
+                            int maxchunks, int weighted, double *mode, double *bw, int *status) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseries) return;
+    const double *st = stats + (size_t)s * KDE_NSTAT;
+    const int n = cnt[s];
+    const bool bad = st[2] > 0.0;
+    const double h = bad ? nan("") : st[7];
+    if (bw) bw[s] = h;
+    if (bad || !(h > 0.0)) { mode[s] = nan(""); status[s] = -1; return; }
+    const int nch = (n + KDE_THREADS - 1) / KDE_THREADS;
+    double a = 0.0, b = 0.0, md = -1.0; int mi = 0;
+    for (int c = 0; c < nch; c++) {
+        const double *o = part + ((size_t)s * maxchunks + c) * 4;
+        a += o[0]; b += o[1];
+        if (o[2] > md) { md = o[2]; mi = (int)o[3]; }
+    }
+    mode[s] = weighted ? a / b : data[off[s] + mi];
+    status[s] = 0;
 }

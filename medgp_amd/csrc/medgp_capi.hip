@@ -1000,21 +1000,31 @@ int medgp_kde_mode(int device, int nseries, const int64_t *off, const int32_t *c
         if (off[s] + cnt[s] > total) total = off[s] + cnt[s];
     }
     HIPCHK(none, hipSetDevice(device));
-    long long *d_off = nullptr; int *d_cnt = nullptr, *d_st = nullptr; double *d_x = nullptr, *d_mode = nullptr, *d_bw = nullptr;
+    long long *d_off = nullptr; int *d_cnt = nullptr, *d_st = nullptr; double *d_x = nullptr, *d_mode = nullptr, *d_bw = nullptr, *d_stats = nullptr, *d_part = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = MEDGP_OK;
     auto chk = [&](hipError_t e, const char *what) { if (e != hipSuccess && rc == MEDGP_OK) rc = fail(none, MEDGP_ERR_HIP, "medgp_kde_mode: %s failed: %s", what, hipGetErrorString(e)); return e == hipSuccess; };
     static_assert(sizeof(long long) == sizeof(int64_t), "offsets are passed through as 64-bit");
+    int maxn = 0;
+    for (int s = 0; s < nseries; s++) maxn = cnt[s] > maxn ? cnt[s] : maxn;
+    const int maxchunks = maxn > 0 ? (maxn + KDE_THREADS - 1) / KDE_THREADS : 1;
     if (chk(hipMalloc(&d_off, sizeof(long long) * nseries), "hipMalloc") && chk(hipMalloc(&d_cnt, sizeof(int) * nseries), "hipMalloc") &&
         chk(hipMalloc(&d_st, sizeof(int) * nseries), "hipMalloc") && chk(hipMalloc(&d_x, sizeof(double) * (total > 0 ? total : 1)), "hipMalloc") &&
         chk(hipMalloc(&d_mode, sizeof(double) * nseries), "hipMalloc") && chk(hipMalloc(&d_bw, sizeof(double) * nseries), "hipMalloc") &&
+        chk(hipMalloc(&d_stats, sizeof(double) * KDE_NSTAT * nseries), "hipMalloc") &&
+        chk(hipMalloc(&d_part, sizeof(double) * 4 * (size_t)nseries * maxchunks), "hipMalloc") &&
         chk(hipEventCreate(&e0), "hipEventCreate") && chk(hipEventCreate(&e1), "hipEventCreate") &&
         chk(hipMemcpy(d_off, off, sizeof(long long) * nseries, hipMemcpyHostToDevice), "hipMemcpy") &&
         chk(hipMemcpy(d_cnt, cnt, sizeof(int) * nseries, hipMemcpyHostToDevice), "hipMemcpy") &&
-        chk(hipMemcpy(d_x, data, sizeof(double) * total, hipMemcpyHostToDevice), "hipMemcpy")) {
+        chk(hipMemcpy(d_x, data, sizeof(double) * total, hipMemcpyHostToDevice), "hipMemcpy") &&
+        chk(hipMemset(d_stats, 0, sizeof(double) * KDE_NSTAT * nseries), "hipMemset")) {
         chk(hipEventRecord(e0, nullptr), "hipEventRecord");
-        hipLaunchKernelGGL(k_kde_mode, dim3(nseries), dim3(KDE_THREADS), 0, nullptr, nseries, d_off, d_cnt, d_x, weighted ? 1 : 0, d_mode, d_bw, d_st);
-        chk(hipGetLastError(), "k_kde_mode launch");
+        hipLaunchKernelGGL(k_kde_stats, dim3(nseries), dim3(KDE_THREADS), 0, nullptr, nseries, d_off, d_cnt, d_x, d_stats);
+        hipLaunchKernelGGL(k_kde_rank, dim3(nseries, maxchunks), dim3(KDE_THREADS), 0, nullptr, d_off, d_cnt, d_x, d_stats);
+        hipLaunchKernelGGL(k_kde_dens, dim3(nseries, maxchunks), dim3(KDE_THREADS), 0, nullptr, d_off, d_cnt, d_x, d_stats, d_part, maxchunks);
+        hipLaunchKernelGGL(k_kde_final, dim3((nseries + 255) / 256), dim3(256), 0, nullptr, nseries, d_off, d_cnt, d_x, d_stats, d_part, maxchunks,
+                           weighted ? 1 : 0, d_mode, d_bw, d_st);
+        chk(hipGetLastError(), "kde kernel launch");
         chk(hipEventRecord(e1, nullptr), "hipEventRecord");
         chk(hipMemcpy(mode, d_mode, sizeof(double) * nseries, hipMemcpyDeviceToHost), "hipMemcpy");
         chk(hipMemcpy(status, d_st, sizeof(int) * nseries, hipMemcpyDeviceToHost), "hipMemcpy");
@@ -1023,7 +1033,7 @@ int medgp_kde_mode(int device, int nseries, const int64_t *off, const int32_t *c
     }
     if (e0) hipEventDestroy(e0);
     if (e1) hipEventDestroy(e1);
-    hipFree(d_off); hipFree(d_cnt); hipFree(d_st); hipFree(d_x); hipFree(d_mode); hipFree(d_bw);
+    hipFree(d_off); hipFree(d_cnt); hipFree(d_st); hipFree(d_x); hipFree(d_mode); hipFree(d_bw); hipFree(d_stats); hipFree(d_part);
     return rc;
 }
 
