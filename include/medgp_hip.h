@@ -172,6 +172,13 @@ int medgp_fit_predict_batch(medgp_ctx *ctx, int nbatch, const int32_t *slots, co
  * bw (the bandwidths) and kernel_ms (HIP-event time of the kernel) may be NULL.  Errors: medgp_last_error(NULL). */
 int medgp_kde_mode(int device, int nseries, const int64_t *off, const int32_t *cnt, const double *data, int weighted,
                    double *mode, double *bw, int32_t *status, double *kernel_ms);
+/* The same with the density of series s evaluated on its own grid test[toff[s] .. toff[s] + tcnt[s]) (tcnt[s] == 0: at the
+ * samples, as above); the mode is then taken over the grid points.  This is how output_mode_SE evaluates the length-scale
+ * (ref: mode_estimate.py:54-57) and output_mode_SM the period / length-scale densities (ref: :170-184): 100001-point grids,
+ * arg-max mode.  toff / tcnt / test are all NULL or all given. */
+int medgp_kde_mode_at(int device, int nseries, const int64_t *off, const int32_t *cnt, const double *data, const int64_t *toff,
+                      const int32_t *tcnt, const double *test, int weighted, double *mode, double *bw, int32_t *status,
+                      double *kernel_ms);
 
 /* block until all work queued on the context's stream is complete */
 int medgp_synchronize(medgp_ctx *ctx);

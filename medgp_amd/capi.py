@@ -22,7 +22,7 @@ SYMBOLS = [
     "medgp_num_hyp", "medgp_set_pi", "medgp_set_stream", "medgp_reserve", "medgp_set_patient",
     "medgp_set_patients", "medgp_set_prior", "medgp_nlml_grad", "medgp_nlml_grad_device", "medgp_get_factor",
     "medgp_factor", "medgp_fit_predict", "medgp_fit_predict_batch", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
-    "medgp_profile_kernel_name", "medgp_profile_read", "medgp_profile_reset", "medgp_kde_mode",
+    "medgp_profile_kernel_name", "medgp_profile_read", "medgp_profile_reset", "medgp_kde_mode", "medgp_kde_mode_at",
 ]
 
 
@@ -85,6 +85,7 @@ def load():
     lib.medgp_profile_read.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_int64)]
     lib.medgp_profile_reset.argtypes = [vp]
     lib.medgp_kde_mode.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int64), i32p, dp, C.c_int, dp, dp, i32p, dp]
+    lib.medgp_kde_mode_at.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int64), i32p, dp, C.POINTER(C.c_int64), i32p, dp, C.c_int, dp, dp, i32p, dp]
     _lib = lib
     return lib
 
@@ -93,20 +94,36 @@ def _ptr(a, ty):
     return None if a is None else a.ctypes.data_as(C.POINTER(ty))
 
 
-def kde_mode(series, weighted=True, device=0, full=False):
-    """medgp_kde_mode over a list of 1-D sample arrays: the KDE "mode" of each (compute_kde + compute_mode of the
-    reference, ref: medgpc/clustering/mode_estimate.py:438-450).  Returns modes [len(series)]; with full=True also
-    (bandwidths, status, kernel milliseconds).  status -1 marks a series the reference's KDE fit raises on."""
-    lib = load()
+def _pack(series):
     ns = len(series)
-    cnt = np.array([len(x) for x in series], dtype=np.int32)
+    cnt = np.array([0 if x is None else np.size(x) for x in series], dtype=np.int32)
     off = np.zeros(ns, dtype=np.int64)
     if ns:
         off[1:] = np.cumsum(cnt[:-1], dtype=np.int64)
-    data = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype=np.float64).ravel() for x in series]) if ns else np.zeros(0))
+    parts = [np.asarray(x, dtype=np.float64).ravel() for x in series if x is not None]
+    data = np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros(0))
+    return off, cnt, data
+
+
+def kde_mode(series, weighted=True, device=0, full=False, test=None):
+    """medgp_kde_mode[_at] over a list of 1-D sample arrays: the KDE "mode" of each (compute_kde + compute_mode of the
+    reference, ref: medgpc/clustering/mode_estimate.py:438-450).  test: optional list (entries may be None) of evaluation
+    grids, one per series -- the density is then evaluated there and the mode taken over the grid.  Returns modes
+    [len(series)]; with full=True also (bandwidths, status, kernel milliseconds).  status -1 marks a series the reference's
+    KDE fit raises on."""
+    lib = load()
+    ns = len(series)
+    off, cnt, data = _pack(series)
     mode, bw, st, ms = np.full(ns, np.nan), np.full(ns, np.nan), np.zeros(ns, dtype=np.int32), C.c_double(0.0)
-    rc = lib.medgp_kde_mode(int(device), ns, _ptr(off, C.c_int64), _ptr(cnt, C.c_int32), _ptr(data, C.c_double),
-                            1 if weighted else 0, _ptr(mode, C.c_double), _ptr(bw, C.c_double), _ptr(st, C.c_int32), C.byref(ms))
+    if test is None:
+        rc = lib.medgp_kde_mode(int(device), ns, _ptr(off, C.c_int64), _ptr(cnt, C.c_int32), _ptr(data, C.c_double),
+                                1 if weighted else 0, _ptr(mode, C.c_double), _ptr(bw, C.c_double), _ptr(st, C.c_int32), C.byref(ms))
+    else:
+        assert len(test) == ns
+        toff, tcnt, tdata = _pack(test)
+        rc = lib.medgp_kde_mode_at(int(device), ns, _ptr(off, C.c_int64), _ptr(cnt, C.c_int32), _ptr(data, C.c_double),
+                                   _ptr(toff, C.c_int64), _ptr(tcnt, C.c_int32), _ptr(tdata, C.c_double), 1 if weighted else 0,
+                                   _ptr(mode, C.c_double), _ptr(bw, C.c_double), _ptr(st, C.c_int32), C.byref(ms))
     if rc != 0:
         raise MedgpError(f"medgp_kde_mode failed ({rc}): {lib.medgp_last_error(None).decode()}")
     return (mode, bw, st, ms.value) if full else mode

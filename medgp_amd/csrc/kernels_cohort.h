@@ -16,7 +16,9 @@
 //                                    statistics -- no sort); the four samples with the wanted ranks are written out
 //   k_kde_dens   (series x chunks)   bandwidth from the statistics; density at the chunk's 256 samples (thread = sample,
 //                                    all n samples staged through LDS in tiles, one fp64 exp per pair -- VALU bound);
-//                                    per-chunk partial sums of x dens and dens (and the chunk's arg max)
+//                                    per-chunk partial sums of x dens and dens (and the chunk's arg max).  The evaluation
+//                                    points can also be a grid of the series' own (output_mode_SE / _SM evaluate the
+//                                    length-scale / period densities on 100001-point grids, ref: :54-57, :170-184)
 //   k_kde_final  (series)            the chunks' partials added in chunk order
 // All sums run in a fixed order: results are bitwise reproducible.
 #pragma once
@@ -102,15 +104,18 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_rank(const long long *off, 
 }
 
 // part[(s * maxchunks + chunk) * 4 + {0: sum x dens, 1: sum dens, 2: best dens, 3: best index}]
-__global__ void __launch_bounds__(KDE_THREADS) k_kde_dens(const long long *off, const int *cnt, const double *data, double *stats,
-                                                          double *part, int maxchunks) {
+// Evaluation points: the samples themselves, or (tcnt != nullptr and tcnt[s] > 0) the series' own grid test[toff[s] ..)
+__global__ void __launch_bounds__(KDE_THREADS) k_kde_dens(const long long *off, const int *cnt, const double *data, const long long *toff,
+                                                          const int *tcnt, const double *test, double *stats, double *part, int maxchunks) {
     __shared__ double tile[KDE_TILE];
     __shared__ double red[KDE_THREADS / 64];
     __shared__ double bestd[KDE_THREADS];
     __shared__ int besti[KDE_THREADS];
     const int s = blockIdx.x, tid = threadIdx.x;
     const int n = cnt[s], i = blockIdx.y * KDE_THREADS + tid;
-    if (blockIdx.y * KDE_THREADS >= n) return;
+    const bool grid = tcnt && tcnt[s] > 0;
+    const int nt = grid ? tcnt[s] : n;
+    if (blockIdx.y * KDE_THREADS >= nt) return;
     double *st = stats + (size_t)s * KDE_NSTAT;
     if (st[2] > 0.0) return;
     int k25, k25h, k75, k75h; double f25, f75;
@@ -124,7 +129,8 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_dens(const long long *off, 
     const double *x = data + off[s];
     const double c2 = -0.5 * MEDGP_LOG2E / (h * h);            // exp(-u^2/2) = 2^(c2 (xj - xi)^2)
     const double norm = 0.3989422804014327 / (h * (double)n);
-    const double xi = (i < n) ? x[i] : 0.0;
+    const double *xt = grid ? test + toff[s] : x;
+    const double xi = (i < nt) ? xt[i] : 0.0;
     double acc = 0.0;
     for (int j0 = 0; j0 < n; j0 += KDE_TILE) {
         const int m = min(KDE_TILE, n - j0);
@@ -137,9 +143,9 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_dens(const long long *off, 
             acc += exp2_nonpos(c2 * (d * d));
         }
     }
-    const double dens = (i < n) ? acc * norm : 0.0;
+    const double dens = (i < nt) ? acc * norm : 0.0;
     const double a = kde_wg_sum(xi * dens, red, tid), b = kde_wg_sum(dens, red, tid);
-    bestd[tid] = (i < n) ? dens : -1.0; besti[tid] = i;
+    bestd[tid] = (i < nt) ? dens : -1.0; besti[tid] = i;
     __syncthreads();
     if (tid == 0) {
         double md = -1.0; int mi = 0;
@@ -151,8 +157,9 @@ __global__ void __launch_bounds__(KDE_THREADS) k_kde_dens(const long long *off, 
 
 // status: 0 ok; -1 not finite / n < 2 / zero bandwidth (the reference's KDEUnivariate.fit raises there and
 // output_mode_kernel exits, ref: mode_estimate.py:23-26)
-__global__ void k_kde_final(int nseries, const long long *off, const int *cnt, const double *data, const double *stats, const double *part,
-                            int maxchunks, int weighted, double *mode, double *bw, int *status) {
+__global__ void k_kde_final(int nseries, const long long *off, const int *cnt, const double *data, const long long *toff, const int *tcnt,
+                            const double *test, const double *stats, const double *part, int maxchunks, int weighted, double *mode,
+                            double *bw, int *status) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nseries) return;
     const double *st = stats + (size_t)s * KDE_NSTAT;
@@ -161,13 +168,16 @@ __global__ void k_kde_final(int nseries, const long long *off, const int *cnt, c
     const double h = bad ? nan("") : st[7];
     if (bw) bw[s] = h;
     if (bad || !(h > 0.0)) { mode[s] = nan(""); status[s] = -1; return; }
-    const int nch = (n + KDE_THREADS - 1) / KDE_THREADS;
+    const bool grid = tcnt && tcnt[s] > 0;
+    const int nt = grid ? tcnt[s] : n;
+    const double *xt = grid ? test + toff[s] : data + off[s];
+    const int nch = (nt + KDE_THREADS - 1) / KDE_THREADS;
     double a = 0.0, b = 0.0, md = -1.0; int mi = 0;
     for (int c = 0; c < nch; c++) {
         const double *o = part + ((size_t)s * maxchunks + c) * 4;
         a += o[0]; b += o[1];
         if (o[2] > md) { md = o[2]; mi = (int)o[3]; }
     }
-    mode[s] = weighted ? a / b : data[off[s] + mi];
+    mode[s] = weighted ? a / b : xt[mi];
     status[s] = 0;
 }

@@ -986,9 +986,16 @@ int medgp_profile_reset(medgp_ctx *c) {
 }
 
 // ---- cohort statistics (no context: a one-shot call on `device`) ----------------------------------------------------------
+int medgp_kde_mode_at(int device, int nseries, const int64_t *off, const int32_t *cnt, const double *data, const int64_t *toff,
+                      const int32_t *tcnt, const double *test, int weighted, double *mode, double *bw, int32_t *status, double *kernel_ms);
 int medgp_kde_mode(int device, int nseries, const int64_t *off, const int32_t *cnt, const double *data, int weighted,
                    double *mode, double *bw, int32_t *status, double *kernel_ms) {
+    return medgp_kde_mode_at(device, nseries, off, cnt, data, nullptr, nullptr, nullptr, weighted, mode, bw, status, kernel_ms);
+}
+int medgp_kde_mode_at(int device, int nseries, const int64_t *off, const int32_t *cnt, const double *data, const int64_t *toff,
+                      const int32_t *tcnt, const double *test, int weighted, double *mode, double *bw, int32_t *status, double *kernel_ms) {
     medgp_ctx *none = nullptr;
+    if ((tcnt != nullptr) != (toff != nullptr) || (tcnt != nullptr) != (test != nullptr)) return fail(none, MEDGP_ERR_ARG, "medgp_kde_mode_at: toff, tcnt and test go together");
     if (nseries < 0 || (nseries > 0 && (!off || !cnt || !data || !mode || !status))) return fail(none, MEDGP_ERR_ARG, "medgp_kde_mode: bad argument");
     if (nseries == 0) return MEDGP_OK;
     int ndev = 0;
@@ -999,7 +1006,15 @@ int medgp_kde_mode(int device, int nseries, const int64_t *off, const int32_t *c
         if (cnt[s] < 0 || off[s] < 0) return fail(none, MEDGP_ERR_ARG, "medgp_kde_mode: series %d has a negative size / offset", s);
         if (off[s] + cnt[s] > total) total = off[s] + cnt[s];
     }
+    int64_t ttotal = 0;
+    int maxnt = 0;
+    for (int s = 0; tcnt && s < nseries; s++) {
+        if (tcnt[s] < 0 || toff[s] < 0) return fail(none, MEDGP_ERR_ARG, "medgp_kde_mode_at: series %d has a negative grid size / offset", s);
+        if (toff[s] + tcnt[s] > ttotal) ttotal = toff[s] + tcnt[s];
+        maxnt = tcnt[s] > maxnt ? tcnt[s] : maxnt;
+    }
     HIPCHK(none, hipSetDevice(device));
+    long long *d_toff = nullptr; int *d_tcnt = nullptr; double *d_test = nullptr;
     long long *d_off = nullptr; int *d_cnt = nullptr, *d_st = nullptr; double *d_x = nullptr, *d_mode = nullptr, *d_bw = nullptr, *d_stats = nullptr, *d_part = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = MEDGP_OK;
@@ -1007,7 +1022,9 @@ int medgp_kde_mode(int device, int nseries, const int64_t *off, const int32_t *c
     static_assert(sizeof(long long) == sizeof(int64_t), "offsets are passed through as 64-bit");
     int maxn = 0;
     for (int s = 0; s < nseries; s++) maxn = cnt[s] > maxn ? cnt[s] : maxn;
-    const int maxchunks = maxn > 0 ? (maxn + KDE_THREADS - 1) / KDE_THREADS : 1;
+    const int rankchunks = maxn > 0 ? (maxn + KDE_THREADS - 1) / KDE_THREADS : 1;
+    const int maxe = maxn > maxnt ? maxn : maxnt;
+    const int maxchunks = maxe > 0 ? (maxe + KDE_THREADS - 1) / KDE_THREADS : 1;
     if (chk(hipMalloc(&d_off, sizeof(long long) * nseries), "hipMalloc") && chk(hipMalloc(&d_cnt, sizeof(int) * nseries), "hipMalloc") &&
         chk(hipMalloc(&d_st, sizeof(int) * nseries), "hipMalloc") && chk(hipMalloc(&d_x, sizeof(double) * (total > 0 ? total : 1)), "hipMalloc") &&
         chk(hipMalloc(&d_mode, sizeof(double) * nseries), "hipMalloc") && chk(hipMalloc(&d_bw, sizeof(double) * nseries), "hipMalloc") &&
@@ -1017,13 +1034,19 @@ int medgp_kde_mode(int device, int nseries, const int64_t *off, const int32_t *c
         chk(hipMemcpy(d_off, off, sizeof(long long) * nseries, hipMemcpyHostToDevice), "hipMemcpy") &&
         chk(hipMemcpy(d_cnt, cnt, sizeof(int) * nseries, hipMemcpyHostToDevice), "hipMemcpy") &&
         chk(hipMemcpy(d_x, data, sizeof(double) * total, hipMemcpyHostToDevice), "hipMemcpy") &&
-        chk(hipMemset(d_stats, 0, sizeof(double) * KDE_NSTAT * nseries), "hipMemset")) {
+        chk(hipMemset(d_stats, 0, sizeof(double) * KDE_NSTAT * nseries), "hipMemset") &&
+        (!tcnt || (chk(hipMalloc(&d_toff, sizeof(long long) * nseries), "hipMalloc") && chk(hipMalloc(&d_tcnt, sizeof(int) * nseries), "hipMalloc") &&
+                   chk(hipMalloc(&d_test, sizeof(double) * (ttotal > 0 ? ttotal : 1)), "hipMalloc") &&
+                   chk(hipMemcpy(d_toff, toff, sizeof(long long) * nseries, hipMemcpyHostToDevice), "hipMemcpy") &&
+                   chk(hipMemcpy(d_tcnt, tcnt, sizeof(int) * nseries, hipMemcpyHostToDevice), "hipMemcpy") &&
+                   chk(hipMemcpy(d_test, test, sizeof(double) * ttotal, hipMemcpyHostToDevice), "hipMemcpy")))) {
         chk(hipEventRecord(e0, nullptr), "hipEventRecord");
         hipLaunchKernelGGL(k_kde_stats, dim3(nseries), dim3(KDE_THREADS), 0, nullptr, nseries, d_off, d_cnt, d_x, d_stats);
-        hipLaunchKernelGGL(k_kde_rank, dim3(nseries, maxchunks), dim3(KDE_THREADS), 0, nullptr, d_off, d_cnt, d_x, d_stats);
-        hipLaunchKernelGGL(k_kde_dens, dim3(nseries, maxchunks), dim3(KDE_THREADS), 0, nullptr, d_off, d_cnt, d_x, d_stats, d_part, maxchunks);
-        hipLaunchKernelGGL(k_kde_final, dim3((nseries + 255) / 256), dim3(256), 0, nullptr, nseries, d_off, d_cnt, d_x, d_stats, d_part, maxchunks,
-                           weighted ? 1 : 0, d_mode, d_bw, d_st);
+        hipLaunchKernelGGL(k_kde_rank, dim3(nseries, rankchunks), dim3(KDE_THREADS), 0, nullptr, d_off, d_cnt, d_x, d_stats);
+        hipLaunchKernelGGL(k_kde_dens, dim3(nseries, maxchunks), dim3(KDE_THREADS), 0, nullptr, d_off, d_cnt, d_x, d_toff, d_tcnt, d_test, d_stats,
+                           d_part, maxchunks);
+        hipLaunchKernelGGL(k_kde_final, dim3((nseries + 255) / 256), dim3(256), 0, nullptr, nseries, d_off, d_cnt, d_x, d_toff, d_tcnt, d_test,
+                           d_stats, d_part, maxchunks, weighted ? 1 : 0, d_mode, d_bw, d_st);
         chk(hipGetLastError(), "kde kernel launch");
         chk(hipEventRecord(e1, nullptr), "hipEventRecord");
         chk(hipMemcpy(mode, d_mode, sizeof(double) * nseries, hipMemcpyDeviceToHost), "hipMemcpy");
@@ -1033,7 +1056,7 @@ int medgp_kde_mode(int device, int nseries, const int64_t *off, const int32_t *c
     }
     if (e0) hipEventDestroy(e0);
     if (e1) hipEventDestroy(e1);
-    hipFree(d_off); hipFree(d_cnt); hipFree(d_st); hipFree(d_x); hipFree(d_mode); hipFree(d_bw); hipFree(d_stats); hipFree(d_part);
+    hipFree(d_off); hipFree(d_cnt); hipFree(d_st); hipFree(d_x); hipFree(d_mode); hipFree(d_bw); hipFree(d_stats); hipFree(d_part); hipFree(d_toff); hipFree(d_tcnt); hipFree(d_test);
     return rc;
 }
 

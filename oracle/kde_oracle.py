@@ -2,6 +2,7 @@
 
     compute_kde / compute_mode   <- medgpc/clustering/mode_estimate.py:438-450
     output_mode_lmc_sm           <- medgpc/clustering/mode_estimate.py:242-435 (numerical part: no directories, files, plots)
+    output_mode_se / _sm         <- medgpc/clustering/mode_estimate.py:29-79 / :82-240
 
 The reference's KDE is statsmodels' KDEUnivariate(kernel="gau", bw="silverman"); statsmodels is a third-party dependency
 (README.md:10, no version pinned) that is absent from /root/reference and from this image, so its PUBLISHED algorithm is
@@ -63,9 +64,48 @@ def compute_mode(data, density, weighted=True):
     return data[np.argmax(density)]
 
 
-def kde_mode(data, weighted=True):
-    dens, _ = compute_kde(data, data)
-    return compute_mode(data, dens, weighted)
+def kde_mode(data, weighted=True, test=None):
+    pts = data if test is None else test
+    dens, _ = compute_kde(data, pts)
+    return compute_mode(pts, dens, weighted)
+
+
+def output_mode_se(hyp_array, mode_fn=kde_mode):
+    """ref: mode_estimate.py:46-61 (hypers: nugget, lengthscale, scalefactor)."""
+    hyp_array = np.asarray(hyp_array, dtype=np.float64)
+    out = np.zeros(hyp_array.shape[1])
+    for i in range(hyp_array.shape[1]):
+        x = np.exp(hyp_array[:, i])
+        if i == 1:                                                   # lengthscale: on a grid, ref :54-57
+            out[i] = np.log(mode_fn(x, False, np.linspace(0.01, 1000.0, 100001)))
+        else:
+            out[i] = np.log(mode_fn(x, False))
+    return out
+
+
+def output_mode_sm(Q, pan_array, hyp_array, mixture_pan, mixture_index, mixture_cluster_num, mixture_cluster_assign, mode_fn=kde_mode):
+    """ref: mode_estimate.py:100-226 (D = 1; hypers: nugget, w_q, mu_q, sqrt v_q)."""
+    pan_array = np.asarray(pan_array)
+    hyp_array = np.asarray(hyp_array, dtype=np.float64)
+    mixture_pan, mixture_index = np.asarray(mixture_pan), np.asarray(mixture_index)
+    mixture_cluster_assign = np.asarray(mixture_cluster_assign)
+    newQ = int(mixture_cluster_num)
+    out = np.zeros(1 + 3 * newQ)
+    out[0] = np.log(mode_fn(np.exp(hyp_array[:, 0]), False))        # ref :108-113
+    row_of = {p: i for i, p in enumerate(pan_array.tolist())}
+    cluster_ids = np.unique(mixture_cluster_assign)
+    assert len(cluster_ids) == newQ
+    per = np.linspace(0.01, 1000.0, 100001)
+    for q, cid in enumerate(cluster_ids):
+        comp = np.where(mixture_cluster_assign == cid)[0]
+        all_mu = np.array([np.exp(hyp_array[row_of[mixture_pan[c]], 1 + Q + mixture_index[c]]) for c in comp])
+        all_v = np.array([np.exp(hyp_array[row_of[mixture_pan[c]], 1 + 2 * Q + mixture_index[c]]) for c in comp])
+        out[1 + newQ + q] = np.log(mode_fn(all_mu, False, 1.0 / per))                       # ref :170-174
+        out[1 + 2 * newQ + q] = np.log(mode_fn(all_v, False, 1.0 / (2.0 * np.pi * per)))    # ref :181-185
+        cpan, cidx = mixture_pan[comp], mixture_index[comp]
+        all_w = np.array([sum(np.exp(hyp_array[row_of[pan], 1 + qq]) for qq in cidx[cpan == pan]) for pan in np.unique(cpan)])
+        out[1 + q] = np.log(mode_fn(all_w, False))                                           # ref :198-226
+    return out
 
 
 def output_mode_lmc_sm(Q, D, R, pan_array, hyp_array, mixture_pan, mixture_index, mixture_cluster_num, mixture_cluster_assign,

@@ -11,11 +11,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from medgp_amd import cohort_mode  # noqa: E402
 from oracle import kde_oracle as KO  # noqa: E402
-from test_cohort_mode import make_cohort  # noqa: E402
-
-
-def oracle_fn(series, weighted):
-    return np.array([KO.kde_mode(s, weighted) for s in series])
+from test_cohort_mode import make_cohort, oracle_fn  # noqa: E402
 
 
 def main():
@@ -32,6 +28,9 @@ def main():
     series = [rng.normal(size=n) for n in (5, 40, 7, 2, 19, 33, 3)]
     m = cohort_mode.kde_modes(series, True, oracle_fn)
     assert np.array_equal(m, oracle_fn(series, True))
+    grids = [None, np.linspace(-3, 3, 50), None, np.linspace(-1, 1, 7), None, None, np.linspace(0, 2, 11)]
+    m = cohort_mode.kde_modes(series, False, oracle_fn, tests=grids)
+    assert np.array_equal(m, oracle_fn(series, False, grids))
     dist.barrier()
     if rank == 0:
         assert os.path.exists(os.path.join(out_dir, "all", "kmeans_mode_param.bin"))

@@ -15,6 +15,11 @@ from medgp_amd import cohort_mode  # noqa: E402
 from oracle import kde_oracle as KO  # noqa: E402
 
 
+def oracle_fn(series, weighted, tests=None):
+    """The oracle as a stand-in for the HIP kernels (kde_fn signature of medgp_amd.cohort_mode)."""
+    return np.array([KO.kde_mode(s, weighted, None if tests is None else tests[i]) for i, s in enumerate(series)])
+
+
 def make_cohort(seed, P, Q, D, R, newQ):
     """Trained hypers of P subjects (string ids, like the reference's cohort id lists) and a component clustering in which
     some subjects have two components in one cluster and some none (both happen in the reference, :360-386)."""
@@ -46,6 +51,8 @@ def test_percentile_and_density_against_scipy():
         g = scipy.stats.gaussian_kde(x, bw_method=h / np.std(x, ddof=1))    # same estimator, driven at the same bandwidth
         pts = np.concatenate([x, rng.normal(size=7)])
         np.testing.assert_allclose(KO.kde_density(x, pts, h), g(pts), rtol=1e-12)
+        grid = np.linspace(-5, 5, 41)                                      # grid evaluation: mode = the densest grid point
+        assert KO.kde_mode(x, False, grid) == grid[np.argmax(g(grid))]
 
 
 def test_silverman_rule_known_answers():
@@ -75,9 +82,9 @@ def test_output_mode_lmc_sm_host_logic_and_files(tmp_path):
     c = make_cohort(1, P=31, Q=3, D=4, R=2, newQ=2)
     calls = []
 
-    def fn(series, weighted):
+    def fn(series, weighted, tests=None):
         calls.append((len(series), weighted))
-        return np.array([KO.kde_mode(s, weighted) for s in series])
+        return oracle_fn(series, weighted, tests)
 
     exp = dict(c["exp"], exp_kernel_dir=str(tmp_path / "kern"))
     got = cohort_mode.output_mode_kernel(2, exp, c["pan"], c["hyp"], c["mpan"], c["midx"], 2, c["assign"], "kmeans", kde_fn=fn)
@@ -90,7 +97,40 @@ def test_output_mode_lmc_sm_host_logic_and_files(tmp_path):
     # layout of the result: the test-time reader expects D + newQ (D R + 2 + D) doubles (ref: c_experiment.cpp:179-219)
     assert len(want) == 4 + 2 * (4 * 2 + 2 + 4)
     with pytest.raises(NotImplementedError):
-        cohort_mode.output_mode_kernel(-1, dict(exp, kernel="SE"), c["pan"], c["hyp"], c["mpan"], c["midx"], 2, c["assign"], "kmeans", kde_fn=fn)
+        cohort_mode.output_mode_kernel(-1, dict(exp, kernel="Matern"), c["pan"], c["hyp"], c["mpan"], c["midx"], 2, c["assign"], "kmeans", kde_fn=fn)
+
+
+def make_sm_cohort(seed, P, Q, newQ):
+    rng = np.random.default_rng(seed)
+    hyp = np.empty((P, 1 + 3 * Q))
+    hyp[:, 0] = np.log(rng.uniform(0.15, 0.4, P))
+    hyp[:, 1:1 + Q] = np.log(rng.uniform(0.05, 1.0, (P, Q)))
+    hyp[:, 1 + Q:1 + 2 * Q] = np.log(1.0 / rng.uniform(12, 72, (P, Q)))
+    hyp[:, 1 + 2 * Q:] = np.log(1.0 / (2 * np.pi * rng.uniform(6, 72, (P, Q))))
+    pan = np.array([f"S{k:04d}" for k in rng.permutation(P)])
+    assign = rng.integers(0, newQ, P * Q)
+    assign[:newQ] = np.arange(newQ)
+    keep = rng.permutation(P * Q)
+    return dict(pan=pan, hyp=hyp, mpan=np.repeat(pan, Q)[keep], midx=np.tile(np.arange(Q), P)[keep], assign=assign[keep],
+                exp={"kernel": "SM", "Q": Q, "D": 1, "R": 1})
+
+
+def test_output_mode_se_and_sm_host_logic(tmp_path):
+    """The univariate families: arg-max modes, length-scale / period densities on the reference's 100001-point grids."""
+    rng = np.random.default_rng(4)
+    hyp = np.log(np.column_stack([rng.uniform(0.1, 0.5, 25), rng.uniform(5, 80, 25), rng.uniform(0.5, 2, 25)]))
+    pan = np.arange(25)
+    exp = {"kernel": "SE", "exp_kernel_dir": str(tmp_path / "se")}
+    got = cohort_mode.output_mode_kernel(-1, exp, pan, hyp, pan, np.zeros(25, int), 1, np.zeros(25, int), "none", kde_fn=oracle_fn)
+    assert np.array_equal(got, KO.output_mode_se(hyp))
+    assert np.exp(got[1]) in np.linspace(0.01, 1000.0, 100001)          # the length-scale mode is a grid point
+    assert np.array_equal(np.fromfile(tmp_path / "se" / "all" / "none_mode_param.bin"), got)
+    c = make_sm_cohort(6, P=21, Q=3, newQ=2)
+    exp = dict(c["exp"], exp_kernel_dir=str(tmp_path / "sm"))
+    got = cohort_mode.output_mode_kernel(0, exp, c["pan"], c["hyp"], c["mpan"], c["midx"], 2, c["assign"], "kmeans", kde_fn=oracle_fn)
+    want = KO.output_mode_sm(3, c["pan"], c["hyp"], c["mpan"], c["midx"], 2, c["assign"])
+    assert np.array_equal(got, want) and len(got) == 1 + 3 * 2
+    assert (tmp_path / "sm" / "fold0" / "kmeans_mode_mixture_num.txt").read_text().split() == ["2"]
 
 
 def test_product_path_has_no_cpu_evaluator():

@@ -38,6 +38,44 @@ def test_kde_mode_ragged_series_vs_oracle():
             assert np.array_equal(mode, want)                          # the arg-max mode is one of the samples
 
 
+def test_kde_mode_on_grids_vs_oracle():
+    """medgp_kde_mode_at: densities on per-series grids (the reference's 100001-point length-scale / period grids), mixed with
+    series evaluated at their samples."""
+    from medgp_amd import capi
+    from oracle import kde_oracle as KO
+    rng = np.random.default_rng(17)
+    per = np.linspace(0.01, 1000.0, 100001)
+    series = [1.0 / rng.uniform(12, 72, 300), rng.normal(size=100), 1.0 / (2 * np.pi * rng.uniform(6, 72, 77)), rng.uniform(5, 80, 40)]
+    grids = [1.0 / per, None, 1.0 / (2 * np.pi * per), per]
+    for weighted in (False, True):
+        mode, bw, st, _ = capi.kde_mode(series, weighted, full=True, test=grids)
+        assert np.all(st == 0)
+        want = np.array([KO.kde_mode(s, weighted, g) for s, g in zip(series, grids)])
+        if weighted:
+            np.testing.assert_allclose(mode, want, rtol=RTOL)
+        else:
+            # arg-max over a fine grid: the densities of neighbouring points differ by less than rounding near the top, so
+            # compare the density AT the chosen points instead of the indices
+            for s, g, m, w in zip(series, grids, mode, want):
+                pts = s if g is None else g
+                assert m in pts
+                h = KO.silverman_bw(s)
+                dm, dw = KO.kde_density(s, np.array([m]), h)[0], KO.kde_density(s, np.array([w]), h)[0]
+                assert abs(dm - dw) <= 1e-13 * dw
+
+
+def test_output_mode_se_sm_on_device(tmp_path):
+    from medgp_amd import cohort_mode
+    from oracle import kde_oracle as KO
+    from test_cohort_mode import make_sm_cohort
+    c = make_sm_cohort(8, P=60, Q=3, newQ=2)
+    exp = dict(c["exp"], exp_kernel_dir=str(tmp_path / "sm"))
+    got = cohort_mode.output_mode_kernel(-1, exp, c["pan"], c["hyp"], c["mpan"], c["midx"], 2, c["assign"], "kmeans")
+    want = KO.output_mode_sm(3, c["pan"], c["hyp"], c["mpan"], c["midx"], 2, c["assign"])
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-4)    # grid spacing 0.01 h: a tie at the top may move one grid point
+    assert np.array_equal(got[:3], want[:3])                     # nugget and weights: arg max over the samples, exact
+
+
 def test_kde_mode_failures_mirror_the_reference_fit():
     from medgp_amd import capi, cohort_mode
     series = [np.ones(9), np.array([3.0]), np.array([1.0, np.nan, 2.0]), np.array([1.0, np.inf]), np.arange(6.0)]
