@@ -71,12 +71,12 @@ struct CholInvSmem {
         double Dk[64][66];             // diagonal phase: in D, out L_kk (lower)
         double St[NW][16 * UPW][CI_ST];   // panel store: per-wave (16 UPW) x 16 slab that turns row-contiguous
                                        // 16-byte global accesses into the transposed accumulator layout
-        struct {                       // end of the history GEMM of pass 0: the waves' partial z products, behind Dk
-            double dk_shadow[64][66];
-            double zpart[NW][64];
-        } zp;
     };
-    double Xk[64][66];             // L_kk^-1 (lower, exact zeros above the diagonal)
+    union {
+        double Xk[64][66];         // L_kk^-1 (lower, exact zeros above the diagonal)
+        double zpart[NW][64];      // end of the history GEMM of pass 0 (the previous step's Xk is dead, the factor has not
+                                   // written the new one yet): the waves' partial z products; wave 0 sums them BEFORE it factors
+    };
     alignas(16) double rhs[64 + 128];          // diag(L_kk) during the factor (+ 128 doubles of diag16 scratch), then the z right-hand side
     double zk[64];                 // z of the current panel (for the in-step alpha accumulation)
     double zs[1024];               // z history kept in LDS for n <= 1024: the in-loop z product then issues no
@@ -705,7 +705,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                         for (int r = 0; r < 4; r++) sm.Dk[16 * wu + li][16 * ct + 4 * r + g] = -acc[ct][0][r];
                 }
-                sm.zp.zpart[wave][lane] = zsum;
+                sm.zpart[wave][lane] = zsum;
                 __syncthreads();
                 STAMP(0);   // wait for the slowest GEMM wave (folded into 0)
                 // one wave factors the block while the co-resident workgroup's waves own the SIMDs (measured at 512 x N=512, two
@@ -713,7 +713,15 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 // register traffic around the out-of-line call in all four waves cost more than its shorter critical path
                 // gains; one workgroup per CU: no difference).  The look-ahead multi-CU schedule, whose diagonal chain IS the
                 // critical path, uses diag_factor_wg.
+                double zacc = 0.0;   // fixed order over the waves' partial products (zpart shares its LDS with Xk: read first)
+                if (wave == 0) {
+#pragma unroll
+                    for (int w2 = 0; w2 < NW; w2++) zacc += sm.zpart[w2][lane];
+                }
 #ifndef CI_EXP_NOFACTOR   // diagnostic build: factor skipped (results meaningless), prices the factor phase
+                // (k_cholinv<8,2> with the factor inlined and 128 VGPRs -- two 8-wave workgroups per CU, four waves per SIMD --
+                //  was tried: alone it matches <8,4> (0.81 ms at 256 patients), but at 128 VGPRs hipcc spills inside the chunk
+                //  loops and 376 scratch operations into the factor: 2.30 ms at 512 patients against 1.38 ms for <4,4>)
                 if (wave == 0) diag_factor_wave((ld_t *)&sm.Dk[0][0], (ld_t *)&sm.Xk[0][0], (ld_t *)sm.rhs, (li_t *)&sm.fail, (ld_t *)&sm.logdet, lane);
 #endif
                 if (wave == 0) {
@@ -721,9 +729,6 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     if (!sm.fail) {
                         // z_k = L_kk^-1 (y_k - zacc).  Xk has exact zeros above the diagonal, so the fixed-length loops
                         // below add the same terms in the same order as triangular loops, but pipeline their LDS reads
-                        double zacc = 0.0;   // fixed order over the waves' partial products
-#pragma unroll
-                        for (int w2 = 0; w2 < NW; w2++) zacc += sm.zp.zpart[w2][lane];
                         sm.rhs[lane] = ((c0 + lane < n) ? y[c0 + lane] : 0.0) - zacc;
                         __builtin_amdgcn_wave_barrier();
                         double s = 0.0;
