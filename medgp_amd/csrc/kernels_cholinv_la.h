@@ -193,7 +193,8 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
 }
 
 // ---- one step ----------------------------------------------------------------------------------------------------------
-// grid = (nbatch, ntask): task 0 = D, tasks 1 .. nF = F (row blocks), then L tasks (row block x slice).
+// grid = (nbatch, ntask): task 0 = D, tasks 1 .. nF = F (row blocks), then L tasks (slice-major: slice x row block, nLrowsL
+// row-block slots per slice as counted by the host for the largest entry).
 // Row-block enumeration for F at step k (panel k is finished, panel k+1 prepared):
 //   M_i, i = k+2 .. nb-1   |  U_rho, rho = 0 .. k (inverse only)  |  Y
 // and for L at step k (partials of panel k+2 over history panels <= k-1; rows that exist in panel k+2 and have such history):
@@ -201,15 +202,21 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
 #ifdef LA_STAMPS
 // diagnostic build (scratch/la_stamps.py): longest workgroup of each role per step (s_memtime ticks = shader cycles), kept in
 // the idle slab of entry 0
+#ifdef LA_STAMPS_ABS   // absolute times instead: slot 7 = earliest start (stored negated for atomicMax), slots 0-2 = latest end per role
+//                        (wall_clock64 = s_memrealtime, 100 MHz, one counter for the whole device; s_memtime differs between XCDs)
+#define LA_T0() const unsigned long long la_t0 = wall_clock64(); if (threadIdx.x == 0) atomicMax((unsigned long long *)L.slab + 8 * k + 7, ~la_t0)
+#define LA_TEND(role) do { if (threadIdx.x == 0) atomicMax((unsigned long long *)L.slab + 8 * k + (role), (unsigned long long)wall_clock64()); } while (0)
+#else
 #define LA_T0() const unsigned long long la_t0 = __builtin_amdgcn_s_memtime()
 #define LA_TEND(role) do { if (threadIdx.x == 0) atomicMax((unsigned long long *)L.slab + 8 * k + (role), __builtin_amdgcn_s_memtime() - la_t0); } while (0)
+#endif
 #define LA_TD(slot) do { if (is_D && threadIdx.x == 0) ((unsigned long long *)L.slab)[8 * k + (slot)] = __builtin_amdgcn_s_memtime() - la_t0; } while (0)
 #else
 #define LA_TD(slot) do {} while (0)
 #define LA_T0() do {} while (0)
 #define LA_TEND(role) do {} while (0)
 #endif
-__global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A, int k, int want_mode) {
+__global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A, int k, int want_mode, int nLrowsL) {
     __shared__ LaSmem sm;
     LA_T0();
     const int b = blockIdx.x;
@@ -240,9 +247,15 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
         else { row.kind = 2; row.blk = 0; }
     } else {
         role = 2;
+        // slice-major, and only the ceil(k / LA_SLICE) slices that exist at this step are launched: the L tasks that have work
+        // are then consecutive in dispatch order, which the hardware deals round-robin over the 8 XCDs.  (Row-major over
+        // maxslice slots per row put the live tasks -- slices 0, 1 of every row early on -- at ids = 0, 1 mod 16, i.e. on TWO
+        // of the eight XCDs, behind ~850 empty workgroups: at N = 4096 the L role ended at 49 us of a step whose diagonal
+        // chain needs 34 us.)
         int t = task - 1 - nF;
-        slice = t % A.maxslice;
-        t /= A.maxslice;
+        slice = t / nLrowsL;
+        t -= slice * nLrowsL;
+        if (slice >= A.maxslice) return;
         const int nU_L = want_inv ? k : 0;
         if (t < nM_F) { row.kind = 0; row.blk = k + 2 + t; }
         else if (t < nM_F + nU_L) { row.kind = 1; row.blk = t - nM_F; }
@@ -276,6 +289,9 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     const double *Xg = A.xk2 + ((size_t)b * 2 + (k & 1)) * 4096;
     const bool is_D = (role == 0);
     if (is_D && !has_next) return;                // the last panel has no next diagonal block
+    // (s_setprio 3 for the diagonal chain, which shares its CU with a bulk workgroup once the chip is full: measured, no effect --
+    //  the chain's cycle count does not change with the load, the shader clock does: 71 k cycles take 29.7 us early and 37.5 us
+    //  from step 16 of N = 4096 on, when more than 256 L workgroups run fp64 MFMA)
     // ---- (0) every global operand of this role is requested up front (X_k, the pre-solve copy P_k+1,k, the role's own block
     //      of panel k, the initial block of panel k+1): one memory round trip instead of four dependent ones on the
     //      critical path of the step; the history product below hides it
@@ -301,12 +317,25 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
         }
         // partial sums over history panels jf .. k-2, written by the L tasks of the previous launch
         const int hist_end = k - 1;               // panels jf .. hist_end-1
-        for (int s = 0; jf + LA_SLICE * s < hist_end; s++) {
-            const double *P = la_part(A, b, (k + 1) & 1, row, s) + (size_t)w * 1024 + lane;
+        // (two slices per iteration, both requested before either is added: the loop is a chain of memory round trips --
+        //  0.9 us per slice on the diagonal chain, 15 slices at the end of N = 4096; the order of the additions is unchanged)
+        const int nsum = (hist_end - jf + LA_SLICE - 1) / LA_SLICE;
+        const double *P0 = la_part(A, b, (k + 1) & 1, row, 0) + (size_t)w * 1024 + lane;
+        int s = 0;
+        for (; s + 1 < nsum; s += 2) {
+            double pa[16], pb[16];
 #pragma unroll
-            for (int ct = 0; ct < 4; ct++)
+            for (int e = 0; e < 16; e++) pa[e] = P0[(size_t)s * 4096 + e * 64];
 #pragma unroll
-                for (int r = 0; r < 4; r++) acc[ct][r] += P[(ct * 4 + r) * 64];
+            for (int e = 0; e < 16; e++) pb[e] = P0[(size_t)(s + 1) * 4096 + e * 64];
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] += pa[e];
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] += pb[e];
+        }
+        if (s < nsum) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] += P0[(size_t)s * 4096 + e * 64];
         }
         // panel k-1 (final since the previous launch)
         if (k >= 1 && jf <= k - 1) la_gemm(Rb, Lb + (size_t)c1 * ld, ld, k - 1, k, acc, sm, tid, w, li, g);

@@ -303,8 +303,9 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
                 for (int k = 0; k < nt64; k++) {
                     const int nMF = std::max(nt64 - (k + 2), 0), nUF = (want_mode & 1) ? k + 1 : 0, nUL = (want_mode & 1) ? k : 0;
                     const int nF = nMF + nUF + 1, nLrows = (k + 2 < nt64 && k >= 1) ? nMF + nUL + 1 : 0;
+                    const int nsl = std::min(la.maxslice, (k + LA_SLICE - 1) / LA_SLICE);   // history slices that exist at step k
                     Launcher l(c, KID_LA_STEP, stream);
-                    hipLaunchKernelGGL(k_la_step, dim3(nbatch, 1 + nF + nLrows * la.maxslice), dim3(LA_THREADS), 0, stream, L, la, k, want_mode);
+                    hipLaunchKernelGGL(k_la_step, dim3(nbatch, 1 + nF + nLrows * nsl), dim3(LA_THREADS), 0, stream, L, la, k, want_mode, nLrows);
                 }
                 { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_finish, dim3(nbatch, 4 * nt64), dim3(256), 0, stream, L, la, want_mode); }
             }
@@ -950,6 +951,11 @@ extern "C" int medgp_debug_read_diag(unsigned long long *out) {
 int medgp_debug_read_slab(medgp_ctx *c, int b, void *out, int nbytes) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, c->dev.slab + (size_t)b * c->dev.slab_stride, nbytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+int medgp_debug_clear_slab(medgp_ctx *c, int b, int nbytes) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemset(c->dev.slab + (size_t)b * c->dev.slab_stride, 0, nbytes));
     return 0;
 }
 int medgp_debug_read_xk(medgp_ctx *c, int b, void *out, int nbytes, int clear) {
