@@ -204,13 +204,17 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
 // the idle slab of entry 0
 #ifdef LA_STAMPS_ABS   // absolute times instead: slot 7 = earliest start (stored negated for atomicMax), slots 0-2 = latest end per role
 //                        (wall_clock64 = s_memrealtime, 100 MHz, one counter for the whole device; s_memtime differs between XCDs)
-#define LA_T0() const unsigned long long la_t0 = wall_clock64(); if (threadIdx.x == 0) atomicMax((unsigned long long *)L.slab + 8 * k + 7, ~la_t0)
+#define LA_T0() const unsigned long long la_t0 = wall_clock64(), la_tm0 = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicMax((unsigned long long *)L.slab + 8 * k + 7, ~la_t0)
 #define LA_TEND(role) do { if (threadIdx.x == 0) atomicMax((unsigned long long *)L.slab + 8 * k + (role), (unsigned long long)wall_clock64()); } while (0)
 #else
 #define LA_T0() const unsigned long long la_t0 = __builtin_amdgcn_s_memtime()
 #define LA_TEND(role) do { if (threadIdx.x == 0) atomicMax((unsigned long long *)L.slab + 8 * k + (role), __builtin_amdgcn_s_memtime() - la_t0); } while (0)
 #endif
+#ifdef LA_STAMPS_ABS
+#define LA_TD(slot) do { if (is_D && threadIdx.x == 0 && (slot) == 6) ((unsigned long long *)L.slab)[8 * k + 6] = __builtin_amdgcn_s_memtime() - la_tm0; } while (0)
+#else
 #define LA_TD(slot) do { if (is_D && threadIdx.x == 0) ((unsigned long long *)L.slab)[8 * k + (slot)] = __builtin_amdgcn_s_memtime() - la_t0; } while (0)
+#endif
 #else
 #define LA_TD(slot) do {} while (0)
 #define LA_T0() do {} while (0)
@@ -289,6 +293,9 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     const double *Xg = A.xk2 + ((size_t)b * 2 + (k & 1)) * 4096;
     const bool is_D = (role == 0);
     if (is_D && !has_next) return;                // the last panel has no next diagonal block
+#ifdef LA_STAMPS_ABS
+    if (is_D && threadIdx.x == 0) ((unsigned long long *)L.slab)[8 * k + 5] = la_t0;   // the chain's own start (wall clock)
+#endif
     // (s_setprio 3 for the diagonal chain, which shares its CU with a bulk workgroup once the chip is full: measured, no effect --
     //  the chain's cycle count does not change with the load, the shader clock does: 71 k cycles take 29.7 us early and 37.5 us
     //  from step 16 of N = 4096 on, when more than 256 L workgroups run fp64 MFMA)

@@ -214,13 +214,23 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
     __shared__ double s_S[EPI_S_MAX], s_A[EPI_A_MAX];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int H = L.H, Q = L.Q, D = L.D, R = L.R, ld = L.ldn;
-    const bool lds_sa = flag_grad && L.kidx == 7 && Q * D * D <= EPI_S_MAX && Q * D * R <= EPI_A_MAX;
+    // grid = (entries, parts): part p owns the hypers [h0, h1) (one workgroup per entry walked H = 2954 hypers of a D = 64
+    // evaluation with 12 dependent 64-term dot products per thread: 0.18 ms of a 3.3 ms evaluation)
+    // The hyper range is cut into nchunk <= MEDGP_EPI_PARTS chunks that depend on H only; a part owns whole chunks, and the prior
+    // log-density is summed per chunk, then over the chunks in order -- the same bits however many parts the host launches.
+    const int part = blockIdx.y, nparts = gridDim.y;
+    const int nchunk = min(MEDGP_EPI_PARTS, (H + 255) / 256), hchunk = (H + nchunk - 1) / nchunk;
+    const int cpp = (nchunk + nparts - 1) / nparts, ch0 = part * cpp, ch1 = min(nchunk, ch0 + cpp);
+    const int h0 = ch0 * hchunk, h1 = min(H, ch1 * hchunk);
+    const int hA0 = L.kidx == 7 ? D : H, hA1 = L.kidx == 7 ? D + Q * D * R : H, hMV1 = L.kidx == 7 ? D + Q * (D * R + 2) : H;
+    const bool own_A = h0 < hA1 && h1 > hA0, own_muv = h0 < hMV1 && h1 > hA1;
+    const bool lds_sa = flag_grad && L.kidx == 7 && own_A && Q * D * D <= EPI_S_MAX && Q * D * R <= EPI_A_MAX;
     const int st = L.status[b];
     double *g = grad_out ? grad_out + (size_t)b * H : nullptr;
-    if (tid == 0 && status_out) status_out[b] = st;
+    if (tid == 0 && part == 0 && status_out) status_out[b] = st;
     if (st < 0) {
-        if (tid == 0) nlml_out[b] = __builtin_nan("");
-        if (flag_grad && g) for (int h = tid; h < H; h += nt) g[h] = __builtin_nan("");
+        if (tid == 0 && part == 0) nlml_out[b] = __builtin_nan("");
+        if (flag_grad && g) for (int h = h0 + tid; h < h1; h += nt) g[h] = __builtin_nan("");
         return;
     }
     const int slot = L.bslot[b], n = L.pn[slot];
@@ -241,7 +251,7 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
     // each (lanes stride over the bins, fixed butterfly) instead of one thread each -- left to single threads they were
     // the critical path of this kernel (300 dependent load pairs at D = 24 while 246 threads idled)
     __shared__ double smuv[64];
-    const bool par_muv = flag_grad && L.kidx == 7 && 2 * Q <= 64;
+    const bool par_muv = flag_grad && L.kidx == 7 && own_muv && 2 * Q <= 64;
     if (par_muv) {
         const int nbins = D * (D + 1) / 2, lane = tid & 63, nwave = nt >> 6;
         for (int w2 = tid >> 6; w2 < 2 * Q; w2 += nwave) {
@@ -261,8 +271,11 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
     // a caller-order copy of a patient (slot + max_slots, nlml-only evaluations) shares the prior of its patient
     const int pslot = slot >= L.max_slots ? slot - L.max_slots : slot;
     const MedgpPrior *pr = L.prior_on[pslot] ? L.prior + (size_t)pslot * H : nullptr;
+    double lp_part = 0.0;   // thread 0: sum of this part's chunk sums, in chunk order
+  for (int ch = ch0; ch < ch1; ch++) {
     double lp_local = 0.0;
-    for (int h = tid; h < H; h += nt) {
+    const int hc1 = min(H, (ch + 1) * hchunk);
+    for (int h = ch * hchunk + tid; h < hc1; h += nt) {
         double gv = 0.0, hv;   // hv = transformed hyper value (what the prior is evaluated at)
         if (L.kidx == 7) {
             if (h < D) {
@@ -338,7 +351,8 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
         if (pr) prior_apply(pr[h], hv, L.pi, flag_grad != 0, lp_local, gv);
         if (flag_grad && g) g[h] = gv;
     }
-    // deterministic reduction of the prior log-density
+    // deterministic reduction of the chunk's prior log-density
+    __syncthreads();
     red[tid] = lp_local;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
@@ -346,8 +360,26 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
         __syncthreads();
     }
     if (tid == 0) {
+        if (nparts > 1) __hip_atomic_store(&L.epi_lp[(size_t)b * MEDGP_EPI_PARTS + ch], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lp_part += red[0];
+    }
+  }
+    if (tid == 0) {
+        double lp = lp_part;
+        if (nparts > 1) {
+            // the chunk sums are added in chunk order by whichever part arrives last (agent-scope atomics: the parts of an entry
+            // may run on different XCDs): the result depends neither on the arrival order nor on the number of parts
+            __threadfence();
+            const int ticket = __hip_atomic_fetch_add(&L.epi_ticket[b], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket != nparts - 1) return;
+            __threadfence();
+            lp = 0.0;
+            for (int c2 = 0; c2 < nchunk; c2++)
+                lp += __hip_atomic_load(&L.epi_lp[(size_t)b * MEDGP_EPI_PARTS + c2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&L.epi_ticket[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         double logdet = L.scal[b * 4 + 0], quad = L.scal[b * 4 + 1];
         double nlml = quad / 2.0 + logdet + n * log(2. * L.pi) / 2.0;   // ref: c_inference_exact.cpp:149-152
-        nlml_out[b] = nlml - red[0];
+        nlml_out[b] = nlml - lp;
     }
 }

@@ -9,6 +9,7 @@
 //                     block sums S, SM, SV [Q][D][D], scalars, status.
 // ldn = max_n rounded up to 64; matrices are row-major with leading dimension ldn.
 #pragma once
+#define MEDGP_EPI_PARTS 16   // k_epilogue splits the H hypers of an entry over up to this many workgroups
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -48,6 +49,8 @@ struct MedgpDev {
     double *scal;            // [batch][4]: logdet, quad, -, -
     int *status;             // [batch]
     int *bn;                 // [batch] n of the entry's patient, written by k_prep (one load instead of the bslot -> pn chain)
+    double *epi_lp;          // [batch][MEDGP_EPI_PARTS] prior log-density of each part of k_epilogue's hyper range
+    int *epi_ticket;         // [batch] arrival counter of those parts (zero between launches: the last part resets it)
     int *jit;                // [batch] jitter rounds applied so far (extra noise additions in the assembly)
     double *xk;              // [batch][64*64] L_kk^-1 of the current panel (multi-CU factorisation)
     double *S, *SM, *SV;     // [batch][Q*D*D]

@@ -24,5 +24,6 @@ for k in range(N // 64):
     ends = [int(a[k, r]) for r in range(3)]
     last = max(ends)
     if k in (0, 1, 2, 4, 8, 9, 16, 17, 32, 33, 48, 60) and start:
+        print(f"        D own start {(int(a[k,5])-start)/100:5.1f} us after the first WG; D start -> factor done: {(int(a[k,6]))/1e3:6.1f} k s_memtime ticks")
         print(f"step {k:2d}: first WG start -> last end of D {(ends[0]-start)/100:6.1f} us  F {(ends[1]-start)/100 if ends[1] else 0:6.1f} us  L {(ends[2]-start)/100 if ends[2] else 0:6.1f} us;  gap since previous step's last end {((start-prev_end)/100 if prev_end else 0):6.1f} us")
     prev_end = last

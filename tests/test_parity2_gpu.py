@@ -296,3 +296,25 @@ def test_medgp_factor_caller_order_and_prefix_property():
         np.testing.assert_allclose(Lm[:p, :p], Lp, rtol=0, atol=1e-11 * np.abs(Lp).max())
         np.testing.assert_allclose(z[:p], np.linalg.solve(Lp, y[:p].astype(np.float64)), rtol=0, atol=1e-10)
     ctx.close()
+
+
+def test_results_do_not_depend_on_batch_size():
+    """The same patient and hypers evaluated alone and as every entry of a 200-entry batch: identical bits.  (Few entries spread
+    k_epilogue's hyper range -- and the prior log-density sum -- over several workgroups, many entries use one; single-block
+    entries are factored by the same kernel in every call.)"""
+    D, N, Q, R = 24, 64, 5, 8
+    m, t, y = synth.patient(77, 0, D, N)
+    th = synth.theta(77, 0, 7, Q, D, R)
+    P = 200
+    ctx = medgp_amd.Context(7, Q, D, R)
+    ctx.reserve(P, N, P)
+    ctx.set_patients(np.arange(P), [(m, t, y)] * P)
+    ctx.set_prior(-1, *synth.hier_gamma_prior(Q, D, R, 0.01))
+    n1, g1, s1 = ctx.nlml_grad([0], th[None], True)
+    nP, gP, sP = ctx.nlml_grad(np.arange(P), np.tile(th, (P, 1)), True)
+    n3, g3, s3 = ctx.nlml_grad([5, 9, 11], np.tile(th, (3, 1)), True)
+    assert s1[0] == 0 and np.all(sP == 0)
+    assert np.all(nP == n1[0]) and np.all(gP == g1[0]) and np.all(n3 == n1[0]) and np.all(g3 == g1[0])
+    ref = O.nlml_grad(7, Q, D, R, m, t, y, th, prior=O.Prior.hier_gamma(Q, D, R, 0.01))
+    assert_parity(n1[0], g1[0], ref, "batch-size invariance")
+    ctx.close()
