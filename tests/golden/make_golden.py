@@ -133,7 +133,32 @@ def fastkernel_gram():
         print(f"fastkernel gram Q={Q} D={D} R={R} N={N}: cond {np.linalg.cond(K + np.diag(np.exp(2 * th[meta]))):.2e}")
 
 
+def fastkernel_univariate():
+    """The single-output families (kernel_index 0 = SE, 8 = SM) composed exactly as the reference's Python does:
+    SE  k(r) = compute_se_1d(s2 = exp(hyp[2]), lc = exp(hyp[1]), r)                       (vizkernel.py:317-320, fastkernel.py:50-54)
+    SM  k(r) = sum_q exp(hyp[1+q]) compute_sm_1d(exp(hyp[1+Q+q]), exp(2 hyp[1+2Q+q]), r)    (vizkernel.py:347-354, fastkernel.py:33-48)
+    evaluated at the pairwise distances of a time vector -> full Gram matrices without the noise diagonal."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_fastkernel", "/root/reference/medgpc/visualization/fastkernel.py")
+    fk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fk)
+    rng = np.random.default_rng(20241002)
+    N = 50
+    t = np.sort(rng.uniform(0, 200, N)).astype(np.float32)
+    dist = np.abs(t.astype(np.float64)[:, None] - t.astype(np.float64)[None, :]).reshape(-1, 1)
+    hyp_se = np.array([np.log(0.3), np.log(25.0), np.log(1.3)])
+    K_se = fk.compute_se_1d(np.exp(hyp_se[2]), np.exp(hyp_se[1]), dist)[:, 0].reshape(N, N)
+    Q = 3
+    hyp_sm = np.concatenate([[np.log(0.25)], np.log(rng.uniform(0.2, 1.0, Q)), np.log(1.0 / rng.uniform(12, 72, Q)),
+                             np.log(1.0 / (2 * np.pi * rng.uniform(6, 72, Q)))])
+    K_sm = np.zeros((N, N))
+    for q in range(Q):
+        K_sm += np.exp(hyp_sm[1 + q]) * fk.compute_sm_1d(np.exp(hyp_sm[1 + Q + q]), np.exp(2 * hyp_sm[1 + 2 * Q + q]), dist)[:, 0].reshape(N, N)
+    np.savez_compressed(os.path.join(HERE, "fastkernel_univariate.npz"), t=t, hyp_se=hyp_se, K_se=K_se, Q=Q, hyp_sm=hyp_sm, K_sm=K_sm)
+    print("fastkernel univariate: SE", K_se.shape, "SM", K_sm.shape)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["appendix_a", "fastkernel", "fastkernel_gram", "config5"]
+    which = sys.argv[1:] or ["appendix_a", "fastkernel", "fastkernel_gram", "fastkernel_univariate", "config5"]
     for w in which:
         globals()[w]()

@@ -89,6 +89,17 @@ def test_oracle_gram_vs_fastkernel_gram(path):
     assert abs(r["nlml"] - ref) <= 1e-11 * abs(ref)
 
 
+@pytest.mark.parametrize("kidx", [0, 8])
+def test_oracle_univariate_gram_vs_fastkernel(kidx):
+    """The single-output families: oracle Gram (kernel_index 0 = SE, 8 = SM) against the reference's Python composition
+    (fastkernel.compute_se_1d / compute_sm_1d as vizkernel.py:317-320, :347-354 call them; make_golden.py::fastkernel_univariate)."""
+    g = np.load(os.path.join(GOLD, "fastkernel_univariate.npz"))
+    t = g["t"]
+    th, Kref, Q = (g["hyp_se"], g["K_se"], 1) if kidx == 0 else (g["hyp_sm"], g["K_sm"], int(g["Q"]))
+    K = O.gram(kidx, Q, 1, 1, np.zeros(t.size, np.int32), t, th, pi=np.pi)
+    np.testing.assert_allclose(K - np.exp(2 * th[0]) * np.eye(t.size), Kref, rtol=0, atol=2e-15 * np.abs(Kref).max())
+
+
 @pytest.mark.parametrize("D,N,Q,R", [(2, 40, 3, 2), (5, 63, 2, 3)])
 def test_oracle_vs_numpy_and_fd(D, N, Q, R):
     m, t, y = synth.patient(3, 0, D, N, interleave=True)

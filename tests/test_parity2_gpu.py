@@ -257,6 +257,30 @@ def test_hip_factor_vs_reference_derived_gram(name):
     ctx.close()
 
 
+@pytest.mark.parametrize("kidx", [0, 8])
+def test_hip_univariate_kernels_vs_reference_python(kidx):
+    """kernel_index 0 (SE) and 8 (SM) on the DEVICE against Gram matrices composed exactly as the reference's Python does
+    (fastkernel.compute_se_1d / compute_sm_1d, vizkernel.py:317-320, :347-354; tests/golden/make_golden.py::fastkernel_univariate)."""
+    g = np.load(os.path.join(GOLD, "fastkernel_univariate.npz"))
+    t = g["t"]
+    N = t.size
+    th, Kref, Q = (g["hyp_se"], g["K_se"], 1) if kidx == 0 else (g["hyp_sm"], g["K_sm"], int(g["Q"]))
+    rng = np.random.default_rng(4)
+    y = rng.normal(size=N).astype(np.float32)
+    m = np.zeros(N, dtype=np.int32)
+    K = Kref + np.exp(2 * th[0]) * np.eye(N)
+    L = sla.cholesky(K, lower=True)
+    yy = y.astype(np.float64)
+    nlml_ref = 0.5 * yy @ sla.cho_solve((L, True), yy) + np.log(np.diag(L)).sum() + 0.5 * N * np.log(2 * np.pi)
+    ctx = make_ctx(kidx, Q, 1, 1, [(m, t, y)])
+    ctx.set_pi(np.pi)
+    nl, _, st = ctx.nlml_grad([0], th[None, :], False)
+    assert st[0] == 0 and abs(nl[0] - nlml_ref) <= 1e-10 * abs(nlml_ref)
+    Ld, _, st = ctx.factor(0, th, N)
+    np.testing.assert_allclose(Ld @ Ld.T, K, rtol=0, atol=1e-12 * np.abs(K).max())
+    ctx.close()
+
+
 def test_packed_upload_equals_single_uploads():
     D, Q, R = 4, 3, 2
     ns = [1, 64, 130, 17, 200, 2]
