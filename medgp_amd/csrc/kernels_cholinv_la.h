@@ -35,6 +35,7 @@ struct LaArgs {
     double *pnx;          // [batch][2][64*64]  copy of the pre-solve block P_k+1,k (row-major), indexed by panel parity: every
                           //                    workgroup of step k re-derives L[C_k+1,C_k] from it while D overwrites the
                           //                    in-place block with the solved values
+    int *flag;            // [batch] step counter of the diagonal chain: k + 1 once the D workgroup of step k is done (parking, below)
     int nbmax;            // 64-blocks of the largest patient of the batch
     int maxslice;         // slices per row block the scratch is dimensioned for
     int rows;             // row blocks the scratch is dimensioned for (2 nbmax + 1)
@@ -159,6 +160,7 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
     if (nb < 2) return;   // single-block entries are factored by k_cholinv (see its only_small switch)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (blockIdx.y == 0 && tid == 0) A.flag[b] = 0;
     if (blockIdx.y >= 1) {
         const int cb = blockIdx.y - 1;
         if (cb >= nb) return;
@@ -220,7 +222,13 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
 #define LA_T0() do {} while (0)
 #define LA_TEND(role) do {} while (0)
 #endif
-__global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A, int k, int want_mode, int nLrowsL) {
+// park >= 0 (single-entry calls): the workgroup with blockIdx.y == park does no work -- it keeps its slot (its LDS) until the
+// diagonal chain of this step is done.  Workgroup 0 (the chain) is dispatched first and lands on the first CU of XCD 0; once every
+// CU holds one workgroup, the next one dispatched to that XCD (id 256) is placed on the same CU, and from then on a bulk (L / F)
+// workgroup shares the chain's CU and its fp64 pipe: the chain slows from 63 k to 82-97 k cycles.  Parked there, a sleeping
+// workgroup costs one of 512 slots and nothing else; if the placement guess is wrong it is merely a wasted slot.  It waits on a
+// flag with a bounded number of polls (no way to hang).
+__global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A, int k, int want_mode, int nLrowsL, int park) {
     __shared__ LaSmem sm;
     LA_T0();
     const int b = blockIdx.x;
@@ -229,13 +237,21 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     const int n = __builtin_amdgcn_readfirstlane(n0);
     const int ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
     if (k >= nb || nb < 2) return;
+    if (park >= 0 && (int)blockIdx.y == park) {
+        if (threadIdx.x >= 64 || k + 1 >= nb) return;   // one wave holds the slot; the last step has no chain
+        for (int it = 0; it < 2000; it++) {              // <= ~3 ms, far beyond any step
+            if (__hip_atomic_load(&A.flag[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > k) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+        return;
+    }
     const int want_inv = want_mode & 1;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *Lb = L.Kmat + (size_t)b * ld * ld, *Ub = L.Linv + (size_t)b * ld * ld;
     const int c0 = 64 * k, c1 = 64 * (k + 1);
     const bool has_next = (k + 1 < nb);
-    int task = blockIdx.y;
+    int task = (park >= 0 && (int)blockIdx.y > park) ? (int)blockIdx.y - 1 : (int)blockIdx.y;
     // the task lists are laid out for the largest patient of the batch (A.nbmax)
     const int nM_F = A.nbmax - (k + 2) > 0 ? A.nbmax - (k + 2) : 0;
     const int nU_F = want_inv ? k + 1 : 0;
@@ -414,7 +430,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     diag_factor_wg((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.Ls[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, w, lane);
     __syncthreads();
     LA_TD(6);
-    if (sm.fail) { if (tid == 0) L.status[b] = -2; return; }
+    if (sm.fail) { if (tid == 0) { L.status[b] = -2; __hip_atomic_store(&A.flag[b], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
     double *Xn = A.xk2 + ((size_t)b * 2 + ((k + 1) & 1)) * 4096;
     for (int e = tid; e < 64 * 64; e += LA_THREADS) {
         const int rr = e >> 6, cc = e & 63;
@@ -422,7 +438,10 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
         if (want_mode) Ub[(size_t)(c1 + rr) * ld + c1 + cc] = (cc >= rr) ? sm.Ls[cc][rr] : 0.0;
         Xn[e] = sm.Ls[rr][cc];
     }
-    if (tid == 0) L.scal[b * 4 + 0] += sm.logdet;   // steps are ordered launches: fixed summation order
+    if (tid == 0) {
+        L.scal[b * 4 + 0] += sm.logdet;   // steps are ordered launches: fixed summation order
+        __hip_atomic_store(&A.flag[b], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // releases the parked workgroup
+    }
     LA_TEND(0);
 }
 

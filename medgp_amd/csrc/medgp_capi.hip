@@ -77,6 +77,8 @@ struct medgp_ctx {
     bool profiling = false;
     bool use_v0 = false;      // MEDGP_V0=1: baseline kernels (debug / A-B parity)
     int cholinv_nw = 0;       // MEDGP_CHOLINV_NW=44|84 forces the workgroup shape (0 = auto)
+    int la_park = 256;        // MEDGP_LA_PARK=<workgroup id>|0: where the look-ahead schedule parks its sleeping workgroup (0 = off)
+    int la_park_maxbatch = 8; // MEDGP_LA_PARK_MAXBATCH: largest batch the parking is used for (measured: 4 x N=2048 -5 %, 16 x N=2048 +2 %)
     int force_mc = 0;         // MEDGP_MULTI_CU=1 forces / -1 forbids the multi-CU factorisation (0 = auto)
     int num_cu = 256;
     int dbg_fail = 0;         // MEDGP_DEBUG_FAIL_ATTEMPTS=k: test hook, see MedgpDev::dbg_fail
@@ -215,7 +217,7 @@ int ensure_la(medgp_ctx *c, int nbatch, int nbmax, LaArgs *out) {
     A.maxslice = (nbmax + LA_SLICE - 1) / LA_SLICE;
     A.rows = 2 * nbmax + 1;
     const size_t need_part = (size_t)nbatch * 2 * A.rows * A.maxslice * 4096;
-    const size_t need_small = (size_t)nbatch * (64 * (size_t)c->ldn + 4 * 4096);
+    const size_t need_small = (size_t)nbatch * (64 * (size_t)c->ldn + 4 * 4096 + 1);
     auto grow = [&](double **p, size_t *cap, size_t need) -> int {
         if (need <= *cap) return MEDGP_OK;
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -236,6 +238,7 @@ int ensure_la(medgp_ctx *c, int nbatch, int nbmax, LaArgs *out) {
     A.ybuf = c->d_la_small;
     A.xk2 = c->d_la_small + (size_t)nbatch * 64 * c->ldn;
     A.pnx = A.xk2 + (size_t)nbatch * 2 * 4096;
+    A.flag = (int *)(A.pnx + (size_t)nbatch * 2 * 4096);
     *out = A;
     return MEDGP_OK;
 }
@@ -304,8 +307,14 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
                     const int nMF = std::max(nt64 - (k + 2), 0), nUF = (want_mode & 1) ? k + 1 : 0, nUL = (want_mode & 1) ? k : 0;
                     const int nF = nMF + nUF + 1, nLrows = (k + 2 < nt64 && k >= 1) ? nMF + nUL + 1 : 0;
                     const int nsl = std::min(la.maxslice, (k + LA_SLICE - 1) / LA_SLICE);   // history slices that exist at step k
+                    // single entry: park a sleeping workgroup where the dispatcher would put the chain's first neighbour (kernels_cholinv_la.h)
+                    const int ntask = 1 + nF + nLrows * nsl;
+                    // (workgroup ids are y * nbatch + x: with nbatch entries the chains are ids 0 .. nbatch-1 and their first neighbours
+                    //  ids 256 .. 256+nbatch-1, i.e. task y = 256 / nbatch of every entry)
+                    const int pk = (c->la_park > 0 && nbatch <= c->la_park_maxbatch && c->la_park % nbatch == 0) ? c->la_park / nbatch : -1;
+                    const int park = (pk > 0 && ntask > pk && k + 1 < nt64) ? pk : -1;
                     Launcher l(c, KID_LA_STEP, stream);
-                    hipLaunchKernelGGL(k_la_step, dim3(nbatch, 1 + nF + nLrows * nsl), dim3(LA_THREADS), 0, stream, L, la, k, want_mode, nLrows);
+                    hipLaunchKernelGGL(k_la_step, dim3(nbatch, ntask + (park >= 0 ? 1 : 0)), dim3(LA_THREADS), 0, stream, L, la, k, want_mode, nLrows, park);
                 }
                 { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_finish, dim3(nbatch, 4 * nt64), dim3(256), 0, stream, L, la, want_mode); }
             }
@@ -467,6 +476,8 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     c->stream = c->own_stream;
     { const char *e = getenv("MEDGP_V0"); c->use_v0 = e && e[0] == '1'; }
     { const char *e = getenv("MEDGP_CHOLINV_NW"); c->cholinv_nw = e ? atoi(e) : 0; }
+    { const char *e = getenv("MEDGP_LA_PARK"); if (e) c->la_park = atoi(e); }
+    { const char *e = getenv("MEDGP_LA_PARK_MAXBATCH"); if (e) c->la_park_maxbatch = atoi(e); }
     { const char *e = getenv("MEDGP_MULTI_CU"); c->force_mc = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_STREAMS"); c->nsplit = e ? atoi(e) : 1; }
     { const char *e = getenv("MEDGP_DEBUG_FAIL_ATTEMPTS"); c->dbg_fail = e ? atoi(e) : 0; }
