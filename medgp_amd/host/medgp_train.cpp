@@ -7,6 +7,7 @@
 //     medgp_train --cfg exp_setup.json --pan-list pans.txt [--device d] [--max-batch B]
 // Outputs per patient (ref :257-323): train_init_hyp_<PAN>.bin, train_hyp_<PAN>.bin, train_var_hyp_<PAN>.bin
 // (prior mode 2), train_num_<PAN>.txt, train_flag_<PAN>.txt.
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -192,12 +193,16 @@ int main(int argc, const char *argv[]) {
     }
     cout << "start doing optimization" << endl;
     long long total_evals = 0, steps = 0;
+    double t_dev = 0.0, t_host = 0.0;   // seconds inside medgp_nlml_grad / in the optimiser state machines (incl. prior uploads)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     while (true) {
         vector<Patient *> act;
         for (Patient *p : running) if (p->active) act.push_back(p);
         if (act.empty()) break;
         for (size_t c0 = 0; c0 < act.size(); c0 += max_batch) {
             const int nb = (int)std::min<size_t>(max_batch, act.size() - c0);
+            const auto t0 = now();
             vector<int32_t> slots(nb), st(nb);
             vector<double> thetas((size_t)nb * H), nl(nb), gr((size_t)nb * H);
             for (int k = 0; k < nb; k++) {
@@ -206,8 +211,14 @@ int main(int argc, const char *argv[]) {
                 const vector<double> &rq = p->use_vem ? p->vem.request() : p->scg.request();
                 std::copy(rq.begin(), rq.end(), thetas.begin() + (size_t)k * H);
             }
+            const auto t1 = now();
             if (medgp_nlml_grad(ctx, nb, slots.data(), thetas.data(), 1, nl.data(), gr.data(), st.data())) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
+            const auto t2 = now();
             total_evals += nb;
+            // (the state machines are independent and were tried under `#pragma omp parallel for`: on the GPU box -- a 16-core cgroup
+            //  quota on a host with many more hardware threads -- libgomp's default team and its spinning workers starved the HIP
+            //  runtime: 0.065 -> 10.4 s of host time and 0.15 -> 1.2 s inside medgp_nlml_grad for 94 steps of 256 patients.  The
+            //  serial loop is 30 % of the optimisation loop's wall time, 9 % of the whole run: left serial.)
             for (int k = 0; k < nb; k++) {
                 Patient *p = act[c0 + k];
                 vector<double> g(gr.begin() + (size_t)k * H, gr.begin() + (size_t)(k + 1) * H);
@@ -221,10 +232,13 @@ int main(int argc, const char *argv[]) {
                     p->active = !p->scg.done();
                 }
             }
+            t_dev += secs(t1, t2);
+            t_host += secs(t0, t1) + secs(t2, now());
         }
         steps++;
     }
     cout << "optimization finished: " << total_evals << " nlml+grad evaluations in " << steps << " lock-step batches" << endl;
+    cout << "INFO: lock-step optimisation: " << t_dev << " s in medgp_nlml_grad, " << t_host << " s in the host optimiser" << endl;
 
     // ---------------- outputs (ref :297-323)
     for (auto &pp : pts) {
