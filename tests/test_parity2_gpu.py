@@ -174,6 +174,26 @@ def test_jitter_exhaustion_mixed_batch_multi_cu(monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("ns", [[1100, 300, 1024, 70], [1216, 1216], [1030, 2, 640, 1100, 64, 900, 130, 1088]])
+def test_look_ahead_small_ragged_batches_vs_oracle(ns, monkeypatch):
+    """The look-ahead schedule with 2, 4 and 8 ragged entries (the batch sizes that use the parked-neighbour workgroup once a
+    step has more than 256 / nbatch tasks per entry), incl. a failing entry (n = 2) and single-block entries in the same call."""
+    monkeypatch.setenv("MEDGP_MULTI_CU", "1")
+    D, Q, R = 3, 2, 2
+    pts = [synth.patient(31, p, D, n) for p, n in enumerate(ns)]
+    ths = np.stack([synth.theta(31, p, 7, Q, D, R) for p in range(len(ns))])
+    ctx = make_ctx(7, Q, D, R, pts, max_batch=8)
+    nlml, grad, st = ctx.nlml_grad(np.arange(len(ns)), ths, True)
+    for p, n in enumerate(ns):
+        ref = O.nlml_grad(7, Q, D, R, *pts[p], ths[p], nthreads=8)
+        assert st[p] == ref["status"], (p, n, st[p], ref["status"])
+        if st[p] >= 0:
+            assert_parity(nlml[p], grad[p], ref, f"ragged look-ahead entry {p} (n={n})")
+    n2, g2, s2 = ctx.nlml_grad(np.arange(len(ns)), ths, True)        # repeatable bit for bit
+    assert np.array_equal(n2[st >= 0], nlml[st >= 0]) and np.array_equal(g2[st >= 0], grad[st >= 0])
+    ctx.close()
+
+
 # ---- the factor boundary ---------------------------------------------------------------------------------------------
 def _reference_predict(kidx, Q, D, R, m, t, alpha, linv, theta, m2, t2):
     """GP_Regression::predict restated with numpy on the reference's buffers (ref: core/gp_regression.cpp:164-196):
