@@ -208,6 +208,28 @@ def other_configs(dev_index, seed, reps=5):
         out[name] = {"patients": P, "N": N, "D": D, "Q": Q, "R": R, "H": H, "ms_per_call": 1e3 * dt, "evals_per_s": P / dt,
                      "frac_fp64_peak": f_alg * P / dt / 1e12 / FP64_PEAK_TFLOPS, "kernel_ms": prof}
         ctx.close()
+    # random-init screening batch (ref: main_one_train.cpp:228-253): 1000 hyper vectors of ONE patient, nlml only
+    D, N, Q, R, P = 24, 512, 5, 8, 1000
+    ctx = medgp_amd.Context(7, Q, D, R, device=dev_index)
+    ctx.reserve(1, N, P)
+    ctx.set_patient(0, *synth.patient(seed + 2, 0, D, N))
+    th = np.stack([synth.theta(seed + 2, s, 7, Q, D, R) for s in range(P)])
+    slots = np.zeros(P, dtype=np.int32)
+    nl, _, st = ctx.nlml_grad(slots, th, False)
+    assert np.all(st >= 0) and np.all(np.isfinite(nl))
+    ctx.nlml_grad(slots, th, False)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.nlml_grad(slots, th, False)
+    dt = (time.perf_counter() - t0) / reps
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    ctx.nlml_grad(slots, th, False)
+    prof = {k: round(v[0], 4) for k, v in ctx.profile_read().items() if v[1] > 0}
+    out["screening_1000xN512_D24_nlml_only"] = {"evaluations": P, "N": N, "D": D, "ms_per_call": 1e3 * dt, "evals_per_s": P / dt,
+                                                "frac_fp64_peak": (N ** 3 / 3 + 2 * N * N + 40 * Q * N * (N + 1) / 2) * P / dt / 1e12 / FP64_PEAK_TFLOPS,
+                                                "kernel_ms": prof}
+    ctx.close()
     # cohort mode estimation: the KDE modes of one cluster of a 4096-subject cohort at D = 24
     # (24 nuggets + mu + v + 300 elements of B; one exp per sample pair -- VALU bound)
     from medgp_amd import capi
