@@ -3,6 +3,9 @@
 //                    (ref: util/c_optimizer_scg.cpp:25-284) on analytic objectives; evaluation budget semantics
 //   hyp  cfg out   : dump c_experiment::get_global_hyp (srand/rand draws) as doubles
 //   data cfg PAN out: dump one patient's (meta, t, y) as loaded + z-scored
+//   cfg  cfg       : print every parsed field of an exp_setup.json + hyp_bound.txt as "key value" lines (tests feed it the
+//                    files the REFERENCE's own writers produced: tests/golden/ref_cfg, medgpc/util/config.py:5-66)
+//   mode cfg fold alg out: dump get_test_kernel_param / get_test_mode_param (ref: dataio/c_experiment.cpp:179-219)
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -272,6 +275,35 @@ int main(int argc, char **argv) {
         printf("DATA %d\n", n);
         return 0;
     }
-    printf("usage: host_logic_test scg | hyp cfg out | data cfg PAN out\n");
+    if (argc >= 3 && !strcmp(argv[1], "cfg")) {
+        c_experiment e;
+        if (!e.load(argv[2])) { printf("ERROR: %s\n", e.error().c_str()); return 1; }
+        const std::vector<int> kp = e.get_kernel_param(), fi = e.get_feature_index();
+        const std::vector<float> ph = e.get_prior_hyp();
+        printf("CFG kernel_index %d\nCFG Q %d\nCFG D %d\nCFG R %d\n", e.get_kernel_index(), kp[0], kp[1], kp[2]);
+        printf("CFG prior_index %d\nCFG cv_fold_num %d\nCFG random_init_num %d\nCFG top_iteration_num %d\nCFG iteration_num_per_update %d\n",
+               e.get_prior_mode(), e.get_cv_fold_num(), e.get_scg_init_num(), e.get_scg_max_iter_num(), e.get_prior_sub_opt_iter());
+        printf("CFG online_learn_rate %.17g\nCFG online_momentum %.17g\n", e.get_online_learn_rate(), e.get_online_momentum());
+        for (size_t i = 0; i < ph.size(); i++) printf("CFG prior_hyp%zu %.9g\n", i, (double)ph[i]);   // float, as GetFloat() narrows them
+        printf("CFG feature_index");
+        for (int f : fi) printf(" %d", f);
+        printf("\nCFG H %d\nCFG lik %d\nCFG cov %d\n", e.get_hyp_num(), e.get_lik_num(), e.get_cov_num());
+        printf("CFG train_dir %s\nCFG test_dir %s\nCFG kernel_dir %s\n", e.get_exp_train_dir().c_str(), e.get_exp_test_dir().c_str(), e.get_exp_kernel_dir().c_str());
+        for (size_t i = 0; i < e.lb().size(); i++) printf("BOUND %zu %.17g %.17g\n", i, e.lb()[i], e.ub()[i]);
+        return 0;
+    }
+    if (argc >= 6 && !strcmp(argv[1], "mode")) {
+        c_experiment e;
+        if (!e.load(argv[2])) { printf("ERROR: %s\n", e.error().c_str()); return 1; }
+        std::vector<int> kp;
+        vec mp;
+        if (!e.get_test_kernel_param(atoi(argv[3]), argv[4], kp) || !e.get_test_mode_param(atoi(argv[3]), argv[4], mp)) { printf("ERROR: %s\n", e.error().c_str()); return 1; }
+        FILE *f = fopen(argv[5], "wb");
+        fwrite(mp.data(), 8, mp.size(), f);
+        fclose(f);
+        printf("MODE Q %d D %d R %d cov %d n %d\n", kp[0], kp[1], kp[2], e.get_test_cov_num(kp), (int)mp.size());
+        return 0;
+    }
+    printf("usage: host_logic_test scg | hyp cfg out | data cfg PAN out | cfg cfg | mode cfg fold alg out\n");
     return 2;
 }

@@ -158,7 +158,53 @@ def fastkernel_univariate():
     print("fastkernel univariate: SE", K_se.shape, "SM", K_sm.shape)
 
 
+def ref_config_files():
+    """The reference's OWN writers (medgpc/util/config.py:5-66, medgpc/util/binaryIO.py:6-10; both importable: os / json /
+    numpy / array only) write the experiment files the C++ host parses: exp_setup.json + hyp_bound.txt for BASELINE config 1
+    (scripts/feature_PT_INR.json, D = 2 -> H = 42) and for the 24-output configs (scripts/feature_all.json, H = 1114), with
+    scripts/opt_prior2.json and the command line of scripts/gen_medgpc_example.sh:11 (LMC-SM, hier-gamma, Q=5, R=8 / 2,
+    eta = beta_lam = 0.01); and a <alg>_mode_param.bin via write_double_to_bin.  The dictionary of path keys is the one
+    run_exp_generator.py:138-163 builds (that module itself needs the cohort files, so it is not run).  Paths are relative to
+    the repository root: the CPU tests run host_logic_test from there."""
+    import importlib.util
+    import json
+
+    def imp(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    cfg = imp("ref_config", "/root/reference/medgpc/util/config.py")
+    bio = imp("ref_binaryIO", "/root/reference/medgpc/util/binaryIO.py")
+    opt = json.load(open("/root/reference/scripts/opt_prior2.json"))
+    for tag, feat_json, R in (("PT_INR", "feature_PT_INR.json", 2), ("all24", "feature_all.json", 8)):
+        feats = [f["index"] for f in json.load(open("/root/reference/scripts/" + feat_json))["feature_list"]]
+        top = f"tests/golden/ref_cfg/{tag}"
+        out = os.path.join(ROOT, top)
+        os.makedirs(out, exist_ok=True)
+        paths = {"exp_top_dir": top, "exp_cfg_dir": top, "exp_log_dir": top + "/log", "exp_train_dir": top + "/train",
+                 "exp_test_dir": top + "/test", "exp_script_dir": top + "/script", "exp_kernel_dir": top + "/kernel",
+                 "exp_figure_dir": top + "/figure", "data_dir": top + "/data", "cohort_id_list": "cohort.txt",
+                 "hyp_bound_file": "hyp_bound.txt"}
+        cfg.write_medgpc_bound(output_dir=out, file_name="hyp_bound.txt", feature_num=len(feats), kernel_index=7,
+                               mixture_num=5, rank_num=R, opt_config=opt)
+        cfg.write_medgpc_config_json(exp_config_file=os.path.join(out, "exp_setup.json"), exp_path_config=paths,
+                                     kernel="LMC-SM", kernel_index=7, feature_list=feats, prior="hier-gamma", prior_index=2,
+                                     eta=0.01, beta_lam=0.01, mixture_num=5, rank_num=R, opt_config=opt, cv_fold_num=10,
+                                     cv_assign_file=top + "/cv_assign.txt")
+        print(f"ref_cfg/{tag}: D={len(feats)} H={len(feats) + 5 * (len(feats) * R + 2 + len(feats))}")
+    # test-time mode kernel of a D=2, Q=3, R=2 experiment: 3 components kept -> H = 2 + 3 (2*2 + 2 + 2) = 26 doubles
+    rng = np.random.default_rng(20241003)
+    mode = rng.normal(0, 0.5, size=26)
+    kd = os.path.join(ROOT, "tests/golden/ref_cfg/PT_INR/kernel/fold0")
+    os.makedirs(kd, exist_ok=True)
+    bio.write_double_to_bin(os.path.join(kd, "gmm_mode_param.bin"), mode)                  # binaryIO.py:6-10
+    np.savetxt(os.path.join(kd, "gmm_mode_mixture_num.txt"), [3], fmt="%d")                # as mode_estimate.py:425
+    np.save(os.path.join(ROOT, "tests/golden/ref_cfg/PT_INR/mode_expected.npy"), mode)
+    print("ref_cfg/PT_INR/kernel/fold0: gmm_mode_param.bin, gmm_mode_mixture_num.txt")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["appendix_a", "fastkernel", "fastkernel_gram", "fastkernel_univariate", "config5"]
+    which = sys.argv[1:] or ["appendix_a", "fastkernel", "fastkernel_gram", "fastkernel_univariate", "config5", "ref_config_files"]
     for w in which:
         globals()[w]()

@@ -120,6 +120,39 @@ def test_oracle_vs_numpy_and_fd(D, N, Q, R):
         assert abs(fd - r["grad"][h]) <= 2e-6 * max(abs(r["grad"][h]), 1e-2 * gs), (h, fd, r["grad"][h])
 
 
+def test_oracle_gradient_all_1114_hypers_richardson_fd():
+    """Rows a14-a19 (W, noise / kernel gradients, gradient order): every one of the 1114 components of the oracle gradient at the
+    headline shape (appendixA_D24_N512: D=24, N=512, Q=5, R=8) against Richardson-extrapolated central differences of the
+    oracle's own nlml (steps 2e-3 and 1e-3; the nlml of this fixture is the value pinned to the compiled reference's printout).
+    4456 nlml-only evaluations on a thread pool (ctypes releases the GIL): about a minute on 8 cores.
+    Observed max error 4.8e-8 relative to max(|g_h|, 1e-3 max|g|); bar 1e-6 (the north star's gradient tolerance)."""
+    from concurrent.futures import ThreadPoolExecutor
+    g = np.load(os.path.join(GOLD, "appendixA_D24_N512.npz"))
+    m, t, y, th, gr = g["meta"], g["t"], g["y"], g["theta"], g["oracle_grad"]
+    assert th.size == 1114
+
+    def f(x):
+        return O.nlml_grad(7, 5, 24, 8, m, t, y, x, flag_grad=False)["nlml"]
+
+    def rich(h, s=2e-3):
+        d = []
+        for step in (s, s / 2):
+            tp, tm = th.copy(), th.copy()
+            tp[h] += step
+            tm[h] -= step
+            d.append((f(tp) - f(tm)) / (2 * step))
+        return (4 * d[1] - d[0]) / 3
+
+    with ThreadPoolExecutor(os.cpu_count() or 4) as ex:
+        fd = np.array(list(ex.map(rich, range(th.size))))
+    gs = np.abs(gr).max()
+    err = np.abs(fd - gr) / np.maximum(np.abs(gr), 1e-3 * gs)
+    assert err.max() <= 1e-6, (int(err.argmax()), err.max())
+    # the per-hyper loop (the reference's algorithm, c_kernel_LMC_SM.cpp:222-325) gives the same 1114 numbers
+    rp = O.nlml_grad(7, 5, 24, 8, m, t, y, th, grad_mode=O.GRAD_PER_HYPER, nthreads=os.cpu_count() or 4)
+    np.testing.assert_allclose(rp["grad"], gr, rtol=1e-9, atol=1e-9 * gs)
+
+
 @pytest.mark.parametrize("kidx,Q", [(8, 3), (0, 1)])
 def test_oracle_single_output_kernels_fd(kidx, Q):
     m, t, y = synth.patient(5, 1, 1, 50)
