@@ -7,7 +7,9 @@ one rank per GPU).  Prints ONE JSON line on rank 0.
 Workload (BASELINE.json metric "per-patient log-lik+grad evals/sec at D=24 N=512"): the per-GPU shard of
 config 4 -- 512 synthetic patients x N=512 observations, D=24 outputs, Q=5, R=8 (H=1114 hypers), LMC-SM kernel,
 Gaussian-MO likelihood, zero mean, hierarchical-gamma prior (mode 2), fp64.  One step = one nlml+gradient
-evaluation of every patient of the shard (one theta each).  Weak scaling: every rank owns 512 patients; the
+evaluation of every patient of the shard (one theta each).  Weak scaling (default): every rank owns 512 patients.
+--scaling strong: the FIXED 4096-patient cohort of BASELINE config 4 is LPT-partitioned over the ranks
+(medgp_amd/shard.py; 4096 / N patients per rank), so the N = 1, 2, 4 lines are that cohort's own numbers.  Either way the
 cohort is sharded with no data-path collective (patients are independent).  Inputs (patients, theta) are
 resident in HBM before the timed region; outputs stay in HBM.
 """
@@ -61,15 +63,18 @@ def csrc_digest():
 
 
 def pmc_traffic(kernel, P, N):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r02_pmc_summary.json: separate
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc_summary.json, latest round: separate
     --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; bytes = counter x 1024, FETCH_SIZE doubled for
     16-byte-per-lane streams as MI355X_MICROARCH.md's HBM section prescribes).  PMC and kernel-trace cannot be combined in
     one run, so the value is measured offline.  It is returned only for the shape it was measured on AND only while the
     device sources are byte-identical to the ones it was measured from (the summary records their digest and the git
     commit); otherwise null -- a stale number is worse than none.  Returns (bytes or None, provenance dict)."""
-    prov = {"file": "profiles/r02_pmc_summary.json"}
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))   # the latest round's passes
+    name = os.path.basename(cands[-1]) if cands else "r03_pmc_summary.json"
+    prov = {"file": "profiles/" + name}
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
     except (OSError, ValueError):
         return None, dict(prov, status="no PMC summary")
     meta = d.get("_meta", {})
@@ -98,7 +103,7 @@ def aggregate_time(t_local, world):
     return float(tt.item())
 
 
-def result_line(value, n_gpus, steps, warmup, ms_per_step, workload, extra):
+def result_line(value, n_gpus, steps, warmup, ms_per_step, workload, extra, scaling="weak"):
     line = {
         "metric": "per-patient nlml+grad evals/sec at D=24 N=512",
         "value": value,
@@ -108,7 +113,7 @@ def result_line(value, n_gpus, steps, warmup, ms_per_step, workload, extra):
         "warmup": warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,   # BASELINE.md holds no published number for this metric
         "dtype": "f64",
         "data": "synthetic",
@@ -177,11 +182,18 @@ def other_configs(dev_index, seed, reps=5):
         ("config3_batched_16xN2048_D24", 24, 2048, 5, 8, 16, 0.0, False),
         ("config5_1xN4096_D64_sparse_prior2", 64, 4096, 5, 8, 1, 0.5, True),
     ]
-    for name, D, N, Q, R, P, sparse, prior in shapes:
+    def guarded(name, fn):
+        """An auxiliary measurement must never cost the headline line: record the failure instead (advisor finding, round 2)."""
+        try:
+            fn()
+        except Exception as e:   # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    def one_shape(name, D, N, Q, R, P, sparse, prior):
         H = synth.num_hyp(7, Q, D, R)
         ctx = medgp_amd.Context(7, Q, D, R, device=dev_index)
         ctx.reserve(P, N, P)
-        nu = min(P, 8)
+        nu = P if P * N <= 65536 else min(P, 8)   # distinct patients (a replicated cohort hides 3-5 % in L2 hits)
         pts = [synth.patient(seed + 1, p, D, N) for p in range(nu)]
         ths = [synth.theta(seed + 1, p, 7, Q, D, R, sparse_frac=sparse) for p in range(nu)]
         ctx.set_patients(np.arange(P), [pts[s % nu] for s in range(P)])
@@ -208,6 +220,17 @@ def other_configs(dev_index, seed, reps=5):
         out[name] = {"patients": P, "N": N, "D": D, "Q": Q, "R": R, "H": H, "ms_per_call": 1e3 * dt, "evals_per_s": P / dt,
                      "frac_fp64_peak": f_alg * P / dt / 1e12 / FP64_PEAK_TFLOPS, "kernel_ms": prof}
         ctx.close()
+
+    for shp in shapes:
+        guarded(shp[0], lambda shp=shp: one_shape(*shp))
+    guarded("screening_1000xN512_D24_nlml_only", lambda: screening(out, dev_index, seed, reps))
+    guarded("cohort_mode_kde_P4096_D24_one_cluster", lambda: cohort_kde(out, dev_index, seed))
+    return out
+
+
+def screening(out, dev_index, seed, reps):
+    import medgp_amd
+    from medgp_amd import synth
     # random-init screening batch (ref: main_one_train.cpp:228-253): 1000 hyper vectors of ONE patient, nlml only
     D, N, Q, R, P = 24, 512, 5, 8, 1000
     ctx = medgp_amd.Context(7, Q, D, R, device=dev_index)
@@ -230,6 +253,9 @@ def other_configs(dev_index, seed, reps=5):
                                                 "frac_fp64_peak": (N ** 3 / 3 + 2 * N * N + 40 * Q * N * (N + 1) / 2) * P / dt / 1e12 / FP64_PEAK_TFLOPS,
                                                 "kernel_ms": prof}
     ctx.close()
+
+
+def cohort_kde(out, dev_index, seed):
     # cohort mode estimation: the KDE modes of one cluster of a 4096-subject cohort at D = 24
     # (24 nuggets + mu + v + 300 elements of B; one exp per sample pair -- VALU bound)
     from medgp_amd import capi
@@ -243,7 +269,6 @@ def other_configs(dev_index, seed, reps=5):
     assert np.all(st == 0)
     out["cohort_mode_kde_P4096_D24_one_cluster"] = {"series": ns, "samples_per_series": Pc, "kernel_ms": kms, "call_ms": 1e3 * dt,
                                                      "gaussian_pair_terms_per_s": ns * Pc * Pc / (kms * 1e-3)}
-    return out
 
 
 def main():
@@ -261,6 +286,10 @@ def main():
     ap.add_argument("--no-prior", action="store_true")
     ap.add_argument("--flag-grad", type=int, default=1)
     ap.add_argument("--no-extra", action="store_true", help="skip the short measurements of BASELINE configs 2, 3, 5")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --patients per GPU (default); strong: the fixed --cohort (BASELINE config 4: 4096 patients) LPT-sharded over the ranks")
+    ap.add_argument("--cohort", type=int, default=4096, help="cohort size of --scaling strong")
+    ap.add_argument("--dump-results", default=None, help="write this rank's (global patient ids, nlml, gradient row sums) to <path>.rank<r>.npz")
     args = ap.parse_args()
 
     import torch
@@ -287,14 +316,21 @@ def main():
 
     D, N, Q, R, P = args.D, args.n, args.Q, args.R, args.patients
     H = synth.num_hyp(7, Q, D, R)
-    first = rank * P   # weak scaling: rank r owns global patients [r*P, (r+1)*P)
+    if args.scaling == "strong":
+        # fixed cohort, static LPT partition by the per-patient cost N^3 + 80 Q N^2 / 2 (uniform N: contiguous-size shards);
+        # ref: one scheduler job per patient, medgpc/util/run_exp_generator.py:213-260
+        from medgp_amd import shard
+        gids = shard.lpt_partition([N] * args.cohort, world, Q)[rank]
+        P = int(gids.size)
+    else:
+        gids = np.arange(rank * P, (rank + 1) * P, dtype=np.int64)   # weak scaling: rank r owns global patients [r*P, (r+1)*P)
     ctx = medgp_amd.Context(7, Q, D, R, device=local_rank)
     ctx.reserve(P, N, P)
     thetas = np.empty((P, H))
     pts = []
     for s in range(P):
-        pts.append(synth.patient(args.seed, first + s, D, N))
-        thetas[s] = synth.theta(args.seed, first + s, 7, Q, D, R)
+        pts.append(synth.patient(args.seed, int(gids[s]), D, N))
+        thetas[s] = synth.theta(args.seed, int(gids[s]), 7, Q, D, R)
     ctx.set_patients(np.arange(P), pts)     # packed upload: one transfer for the whole shard
     if not args.no_prior:
         ctx.set_prior(-1, *synth.hier_gamma_prior(Q, D, R, 0.01))
@@ -335,9 +371,23 @@ def main():
     st = stat_d.cpu().numpy()
     nl = nlml_d.cpu().numpy()
     assert np.all(st >= 0) and np.all(np.isfinite(nl)), "evaluation failed inside the timed region"
+    if args.dump_results:
+        np.savez(f"{args.dump_results}.rank{rank}.npz", gids=gids, nlml=nl, gsum=grad_d.sum(dim=1).cpu().numpy(), status=st)
+    # who actually ran: (rank, device index, device name, uuid, host) of every rank, gathered once outside the timed region
+    props = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "device": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+          "host": os.uname().nodename, "patients": int(P)}
+    if world > 1:
+        import torch.distributed as dist
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        backend = dist.get_backend()
+    else:
+        seen, backend = [me], "none"
 
     if rank == 0:
-        value = world * P * args.steps / t
+        total_patients = sum(r["patients"] for r in seen)
+        value = total_patients * args.steps / t
         # dominant kernel + roofline from the live HIP-event timings
         tot = {k: v[0] for k, v in prof.items() if v[1] > 0}
         dom = max(tot, key=tot.get)
@@ -356,6 +406,7 @@ def main():
                      "kernel_ms_per_step": {k: round(v[0] / max(args.steps, 1), 4) for k, v in prof.items() if v[1] > 0}})
         f_alg = N ** 3 + 6 * N * N + 80 * Q * N * (N + 1) / 2
         extra = {
+            "ranks_seen": seen, "backend": backend,
             "roofline": roof,
             "end_to_end": {"flop_per_eval": f_alg, "tflops": f_alg * value / world / 1e12,
                            "frac_fp64_peak": f_alg * value / world / 1e12 / FP64_PEAK_TFLOPS},
@@ -364,10 +415,12 @@ def main():
             extra["other_configs"] = other_configs(local_rank, args.seed)
         if world == 1 and not args.no_cpu_baseline:
             extra["cpu_baseline"] = cpu_baseline(D, N, Q, R, args.seed)
+        what = (f"config 4 cohort: {total_patients} patients LPT-sharded over {world} GPU(s) ({P} on rank 0)" if args.scaling == "strong"
+                else f"config 4 shard: {P} patients/GPU")
         line = result_line(value, world, args.steps, args.warmup, 1e3 * t / args.steps,
-                           f"config 4 shard: {P} patients/GPU x N={N}, D={D}, Q={Q}, R={R}, H={H}, LMC-SM + hier-gamma prior, nlml+grad",
-                           extra)
-        line["config"].update({"patients_per_gpu": P, "N": N, "D": D, "Q": Q, "R": R, "H": H,
+                           f"{what} x N={N}, D={D}, Q={Q}, R={R}, H={H}, LMC-SM + hier-gamma prior, nlml+grad",
+                           extra, scaling=args.scaling)
+        line["config"].update({"patients_per_gpu": P, "cohort": total_patients, "N": N, "D": D, "Q": Q, "R": R, "H": H,
                                "parallelism": f"patient-sharded x{world} (no collective)"})
         print(json.dumps(line), flush=True)
     ctx.close()

@@ -105,6 +105,13 @@ int medgp_set_patients(medgp_ctx *ctx, int nslots, const int32_t *slots, const i
 int medgp_set_prior(medgp_ctx *ctx, int slot, const uint8_t *flag, const int32_t *type,
                     const uint8_t *is_exp, const float *p0, const float *p1);
 
+/* The same for nslots slots in ONE host-to-device transfer and without waiting for the device: row k of the [nslots][H] arrays
+ * describes slot slots[k] (flag == NULL removes the prior of all of them).  This is what a cohort trainer calls once per
+ * variational-EM outer iteration for every patient whose psi changed -- the reference rebuilds the public vectors of one
+ * c_prior object per patient there, ref: util/c_optimizer_varEM.cpp:98-162, prior/c_prior.cpp:222-279. */
+int medgp_set_priors(medgp_ctx *ctx, int nslots, const int32_t *slots, const uint8_t *flag, const int32_t *type,
+                     const uint8_t *is_exp, const float *p0, const float *p1);
+
 /* THE OPERATOR.  nbatch independent evaluations: problem b = patient slots[b] with hypers
  * theta[b*H .. (b+1)*H).  Replaces c_objective_one::compute_objective -> GP_Regression::train ->
  * c_inference_prior::compute_nlml -> c_inference_exact::compute_nlml,
@@ -127,6 +134,19 @@ int medgp_nlml_grad(medgp_ctx *ctx, int nbatch, const int32_t *slots, const doub
  * still produced on the stream, but the call itself waits for the factorisation. */
 int medgp_nlml_grad_device(medgp_ctx *ctx, int nbatch, const int32_t *slots, const double *theta_dev,
                            int flag_grad, double *nlml_dev, double *grad_dev, int32_t *status_dev);
+
+/* Asynchronous form of medgp_nlml_grad for hosts that overlap their own work (the optimiser state machines of the patients of
+ * one half of a cohort, ref: util/c_optimizer_scg.cpp:87-281) with the device working on the other half: the call queues the
+ * theta upload, the evaluation and the result downloads of `lane` (0 or 1; each lane has its own device staging) on the context's
+ * stream and returns; medgp_wait(ctx, lane) blocks until that lane's results are in nlml / grad / status.  The host arrays must
+ * stay valid (and untouched) until then, and overlap needs them in pinned memory: medgp_host_alloc / medgp_host_free
+ * (hipHostMalloc; pageable memory works but makes the copies synchronous).  A lane holds one call at a time.  Calls that take
+ * the multi-CU schedule (see medgp_nlml_grad_device) may block until their factorisation has finished. */
+void *medgp_host_alloc(size_t bytes);
+void  medgp_host_free(void *p);
+int   medgp_nlml_grad_async(medgp_ctx *ctx, int lane, int nbatch, const int32_t *slots, const double *theta, int flag_grad,
+                            double *nlml, double *grad, int32_t *status);
+int   medgp_wait(medgp_ctx *ctx, int lane);
 
 /* After medgp_nlml_grad*(…, flag_grad with MEDGP_FLAG_GRAD or MEDGP_FLAG_KEEP_FACTOR): copy out K^-1 (y - m), L^-1 and
  * beta = (y - m)^T K^-1 (y - m) of batch entry b as the reference's float buffers (alpha[n]; linv[n*n] row-major lower,

@@ -20,7 +20,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SYMBOLS = [
     "medgp_abi_version", "medgp_device_count", "medgp_create", "medgp_destroy", "medgp_last_error",
     "medgp_num_hyp", "medgp_set_pi", "medgp_set_stream", "medgp_reserve", "medgp_set_patient",
-    "medgp_set_patients", "medgp_set_prior", "medgp_nlml_grad", "medgp_nlml_grad_device", "medgp_get_factor",
+    "medgp_set_patients", "medgp_set_prior", "medgp_set_priors", "medgp_host_alloc", "medgp_host_free", "medgp_nlml_grad_async",
+    "medgp_wait", "medgp_nlml_grad", "medgp_nlml_grad_device", "medgp_get_factor",
     "medgp_factor", "medgp_fit_predict", "medgp_fit_predict_batch", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
     "medgp_profile_kernel_name", "medgp_profile_read", "medgp_profile_reset", "medgp_kde_mode", "medgp_kde_mode_at",
 ]
@@ -71,6 +72,13 @@ def load():
     lib.medgp_set_patient.argtypes = [vp, C.c_int, C.c_int, i32p, fp, fp]
     lib.medgp_set_patients.argtypes = [vp, C.c_int, i32p, C.POINTER(C.c_int64), i32p, fp, fp]
     lib.medgp_set_prior.argtypes = [vp, C.c_int, u8p, i32p, u8p, fp, fp]
+    lib.medgp_set_priors.argtypes = [vp, C.c_int, i32p, u8p, i32p, u8p, fp, fp]
+    lib.medgp_host_alloc.argtypes = [C.c_size_t]
+    lib.medgp_host_alloc.restype = vp
+    lib.medgp_host_free.argtypes = [vp]
+    lib.medgp_host_free.restype = None
+    lib.medgp_nlml_grad_async.argtypes = [vp, C.c_int, C.c_int, i32p, vp, C.c_int, vp, vp, vp]
+    lib.medgp_wait.argtypes = [vp, C.c_int]
     lib.medgp_nlml_grad.argtypes = [vp, C.c_int, i32p, dp, C.c_int, dp, dp, i32p]
     lib.medgp_nlml_grad_device.argtypes = [vp, C.c_int, i32p, vp, C.c_int, vp, vp, vp]
     lib.medgp_get_factor.argtypes = [vp, C.c_int, fp, fp, fp]
@@ -150,6 +158,9 @@ class Context:
         if getattr(self, "_h", None):
             self._lib.medgp_destroy(self._h)
             self._h = None
+            for p in getattr(self, "_pinned", []):
+                self._lib.medgp_host_free(p)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -199,6 +210,39 @@ class Context:
         assert flag.shape[0] == self.H
         self._chk(self._lib.medgp_set_prior(self._h, int(slot), _ptr(flag, C.c_uint8), _ptr(type, C.c_int32),
                                             _ptr(is_exp, C.c_uint8), _ptr(p0, C.c_float), _ptr(p1, C.c_float)))
+
+    def set_priors(self, slots, flag=None, type=None, is_exp=None, p0=None, p1=None):
+        """Batched medgp_set_prior: arrays are [len(slots), H]; one transfer, no device wait."""
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        ns = slots.shape[0]
+        if flag is None:
+            self._chk(self._lib.medgp_set_priors(self._h, ns, _ptr(slots, C.c_int32), None, None, None, None, None))
+            return
+        arrs = [np.ascontiguousarray(a, dtype=dt).reshape(ns, self.H) for a, dt in
+                ((flag, np.uint8), (type, np.int32), (is_exp, np.uint8), (p0, np.float32), (p1, np.float32))]
+        self._chk(self._lib.medgp_set_priors(self._h, ns, _ptr(slots, C.c_int32), _ptr(arrs[0], C.c_uint8), _ptr(arrs[1], C.c_int32),
+                                             _ptr(arrs[2], C.c_uint8), _ptr(arrs[3], C.c_float), _ptr(arrs[4], C.c_float)))
+
+    def pinned(self, shape, dtype):
+        """numpy array in pinned host memory (medgp_host_alloc); freed with the context."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self._lib.medgp_host_alloc(max(n, 1))
+        if not p:
+            raise MedgpError("medgp_host_alloc failed")
+        self._pinned = getattr(self, "_pinned", []) + [p]
+        buf = (C.c_char * max(n, 1)).from_address(p)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def nlml_grad_async(self, lane, slots, theta, flag_grad, nlml, grad, status):
+        """medgp_nlml_grad_async: theta / nlml / grad / status are (pinned) numpy arrays that stay alive until wait(lane)."""
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        self._chk(self._lib.medgp_nlml_grad_async(self._h, int(lane), slots.shape[0], _ptr(slots, C.c_int32),
+                                                  C.c_void_p(theta.ctypes.data), int(bool(flag_grad)), C.c_void_p(nlml.ctypes.data),
+                                                  C.c_void_p(grad.ctypes.data if grad is not None else 0),
+                                                  C.c_void_p(status.ctypes.data if status is not None else 0)))
+
+    def wait(self, lane):
+        self._chk(self._lib.medgp_wait(self._h, int(lane)))
 
     def nlml_grad(self, slots, theta, flag_grad=True, keep_factor=False):
         """Host-pointer operator. theta: [nbatch, H]. Returns (nlml[nbatch], grad[nbatch,H] or None, status[nbatch]).

@@ -78,7 +78,25 @@ def kde_modes(series, weighted=True, kde_fn=None, device=None, group=None, tests
     owner = deal_series(cost, world)
     mine = np.where(owner == rank)[0]
     sub_t = None if tests is None else [tests[i] for i in mine]
-    local = np.asarray(kde_fn([series[i] for i in mine], weighted, sub_t), dtype=np.float64) if len(mine) else np.zeros(0)
+    # A failing series (KDEUnivariate.fit raises; the reference exits the whole program there, ref: mode_estimate.py:23-26) is
+    # local to the rank that owns it.  Every rank must still take part in the SAME sequence of collectives: catch the local
+    # error, agree on failure with one all_reduce(MAX), then raise on EVERY rank -- otherwise the healthy ranks would sit in
+    # the all_gather until the process group times out.
+    err, local = None, np.zeros(0)
+    try:
+        if len(mine):
+            local = np.asarray(kde_fn([series[i] for i in mine], weighted, sub_t), dtype=np.float64)
+    except Exception as e:   # noqa: BLE001 -- any local failure must reach the collective below
+        err = e
+    import torch
+    flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        flag = flag.cuda()
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag.item()):
+        if err is not None:
+            raise err
+        raise capi.MedgpError("KDE fit failed on another rank (see that rank's message)")
     parts = _all_gather_padded(local, group)
     out = np.full(len(series), np.nan)
     for r in range(world):

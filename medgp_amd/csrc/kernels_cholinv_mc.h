@@ -8,8 +8,10 @@
 // The kernel boundary is the grid-wide synchronisation (about 2 us each, 2 N/64 of them).
 // The reference's jitter loop (ref: inference/c_inference_exact.cpp:99-108) is driven from the host here: a failed
 // pivot marks the problem (status -2), the host bumps its jitter count and re-runs assembly + factorisation.
+// A/B code: compiled only with -DMEDGP_LEGACY_AB (make LEGACY=1); MEDGP_MC_OLD=1 then selects it at run time.
 #pragma once
 #include "kernels_cholinv.h"
+#ifdef MEDGP_LEGACY_AB
 
 #define MC_KC 32
 #define MC_THREADS 256
@@ -232,3 +234,4 @@ __global__ void __launch_bounds__(256) k_ci_finish(MedgpDev L) {
         L.status[b] = L.jit[b];
     }
 }
+#endif  // MEDGP_LEGACY_AB

@@ -33,6 +33,16 @@ __global__ void __launch_bounds__(256) k_scatter_patients(const char *__restrict
     if (tid == 0) pn[slot] = n;
 }
 
+// Prior descriptors (ref: prior/c_prior.h:35-53): row blockIdx.x of the staged rows goes to slot slots[blockIdx.x]; with
+// slots == NULL the ONE staged row is replicated into slot blockIdx.x (medgp_set_prior(slot = -1)).
+__global__ void __launch_bounds__(256) k_scatter_priors(const MedgpPrior *__restrict__ rows, const int *__restrict__ slots, int H,
+                                                        MedgpPrior *prior, uint8_t *prior_on, uint8_t on) {
+    const int k = blockIdx.x, slot = slots ? slots[k] : k;
+    const MedgpPrior *src = rows + (slots ? (size_t)k * H : 0);
+    for (int h = threadIdx.x; h < H; h += blockDim.x) prior[(size_t)slot * H + h] = src[h];
+    if (threadIdx.x == 0) prior_on[slot] = on;
+}
+
 // ------------------------------------------------------------------------------------------
 // predict: mean* = k*^T K^-1 y = v^T z,  var* = k** - v^T v + sigma^2,  v = L^-1 k*,  z = L^-1 y
 //   ref: core/gp_regression.cpp:128-214 (sgemv with chol_alpha, strmm with chol_factor_inv, sdsdot),

@@ -1,6 +1,8 @@
-// kernels_v0.h -- the first correct HIP statement of the dense stages (no MFMA, simple tiling): Gram assembly, Cholesky +
-// forward solve, triangular inverse, W = U U^T - alpha alpha^T, block sums.  Kept as an A/B path (MEDGP_V0=1) and as the
-// generic route for Q > 8; checked against the same oracle as the tuned kernels.
+// kernels_v0.h -- the first correct HIP statement of the stages (no MFMA, simple tiling).  Product code: the generic route for
+// Q > 8 mixture components (k_assemble_v0, k_lauum_v0, k_gradbins_v0 -- the tuned kernels are instantiated for Q <= 8), checked
+// against the same oracle as the tuned kernels (tests/test_parity_gpu.py, Q = 9).  The first-generation dense kernels
+// (k_potrf_v0, k_trtri_v0: Cholesky + forward solve, triangular inverse) are A/B code and only compiled with
+// -DMEDGP_LEGACY_AB (make LEGACY=1 builds such a library; MEDGP_V0=1 then selects them at run time).
 #pragma once
 #include "kernels_core.h"
 
@@ -36,6 +38,7 @@ __global__ void __launch_bounds__(256) k_assemble_v0(MedgpDev L) {
 
 // whole-matrix re-assembly by one workgroup with `count` extra noise additions (jitter path)
 //   ref: c_inference_exact.cpp:99-108
+#ifdef MEDGP_LEGACY_AB
 // ------------------------------------------------------------------------------------------
 // stage 2: Cholesky (lower, in place) + forward solve z = L^-1 y + log-det + quad, with the
 // reference's jitter-retry loop.  Right-looking, 16-wide panels, one workgroup per problem.
@@ -222,6 +225,8 @@ __global__ void __launch_bounds__(256) k_trtri_v0(MedgpDev L) {
     }
 }
 #undef XU
+
+#endif  // MEDGP_LEGACY_AB
 
 // ------------------------------------------------------------------------------------------
 // stage 4: W = L^-T L^-1 - alpha alpha^T = U U^T - alpha alpha^T, lower 64x64 tiles, written over the (dead) L buffer

@@ -47,8 +47,23 @@ struct medgp_ctx {
     double *d_pt = nullptr, *d_py = nullptr;
     MedgpPrior *d_prior = nullptr;
     uint8_t *d_prior_on = nullptr;
-    double *d_theta = nullptr, *d_nlml = nullptr, *d_grad = nullptr;   // staging for the host-pointer API
+    double *d_theta = nullptr, *d_nlml = nullptr, *d_grad = nullptr;   // staging for the host-pointer API (= lane 0)
     int *d_status_out = nullptr;
+    // second lane of the asynchronous host-pointer API (medgp_nlml_grad_async): lane 0 uses the buffers above
+    double *d_theta1 = nullptr, *d_nlml1 = nullptr, *d_grad1 = nullptr;
+    int *d_status1 = nullptr;
+    hipEvent_t ev_lane[2] = {nullptr, nullptr};
+    bool lane_pending[2] = {false, false};
+    // pinned staging ring for small host-to-device uploads (slot tables, prior descriptors): the source of an asynchronous
+    // copy must stay untouched until the copy has run, and nothing here waits for the device on the normal path
+    char *pin_buf[2] = {nullptr, nullptr};
+    size_t pin_cap = 0, pin_off = 0;
+    int pin_cur = 0;
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_pending[2] = {false, false};
+    MedgpPrior *d_prior_stage = nullptr;   // device staging of medgp_set_prior[s] rows
+    int *d_prior_slots = nullptr;
+    size_t prior_stage_rows = 0;
     // host mirrors
     std::vector<int> h_n;
     std::vector<std::vector<int>> h_perm;   // internal index -> caller index
@@ -86,6 +101,7 @@ struct medgp_ctx {
     hipStream_t aux[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     std::vector<EvPair> events;
+    std::vector<hipEvent_t> ev_pool;   // recycled timing events: a profiled launch creates none once the pool is warm
     double prof_ms[KID_COUNT] = {0};
     int64_t prof_n[KID_COUNT] = {0};
     std::string err;
@@ -140,16 +156,21 @@ struct Launcher {
     hipEvent_t a = nullptr, b = nullptr;
     Launcher(medgp_ctx *c_, int kid_, hipStream_t st_ = nullptr) : c(c_), kid(kid_), st(st_ ? st_ : c_->stream) {
         if (c->profiling) {
-            (void)hipEventCreate(&a);
-            (void)hipEventCreate(&b);
+            a = take(); b = take();
             (void)hipEventRecord(a, st);
         }
+    }
+    hipEvent_t take() {
+        hipEvent_t e = nullptr;
+        if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
     }
     ~Launcher() {
         if (c->profiling) {
             (void)hipEventRecord(b, st);
             if (kid >= 0) c->events.push_back({kid, a, b});
-            else { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+            else { c->ev_pool.push_back(a); c->ev_pool.push_back(b); }   // recorded but never read: safe to re-record later
         }
     }
 };
@@ -162,10 +183,35 @@ int drain_events(medgp_ctx *c) {
             c->prof_ms[e.kid] += ms;
             c->prof_n[e.kid] += 1;
         }
-        (void)hipEventDestroy(e.a);
-        (void)hipEventDestroy(e.b);
+        c->ev_pool.push_back(e.a);
+        c->ev_pool.push_back(e.b);
     }
     c->events.clear();
+    return MEDGP_OK;
+}
+
+// A pinned region of `bytes` that stays untouched until every copy queued from it on c->stream so far has run.  Two buffers:
+// when one is full its event is recorded and the other one is taken (waiting only if THAT buffer's copies from a whole
+// ring revolution ago are still in flight, which in practice never happens).
+int pin_stage(medgp_ctx *c, size_t bytes, void **out) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (bytes > c->pin_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < 2; i++) { if (c->pin_buf[i]) (void)hipHostFree(c->pin_buf[i]); c->pin_buf[i] = nullptr; c->pin_pending[i] = false; }
+        const size_t cap = std::max<size_t>(2 * bytes, (size_t)1 << 20);
+        for (int i = 0; i < 2; i++) HIPCHK(c, hipHostMalloc((void **)&c->pin_buf[i], cap, hipHostMallocDefault));
+        c->pin_cap = cap; c->pin_off = 0; c->pin_cur = 0;
+    }
+    for (int i = 0; i < 2; i++) if (!c->pin_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+    if (c->pin_off + bytes > c->pin_cap) {
+        HIPCHK(c, hipEventRecord(c->pin_ev[c->pin_cur], c->stream));
+        c->pin_pending[c->pin_cur] = true;
+        c->pin_cur ^= 1;
+        if (c->pin_pending[c->pin_cur]) { HIPCHK(c, hipEventSynchronize(c->pin_ev[c->pin_cur])); c->pin_pending[c->pin_cur] = false; }
+        c->pin_off = 0;
+    }
+    *out = c->pin_buf[c->pin_cur] + c->pin_off;
+    c->pin_off += bytes;
     return MEDGP_OK;
 }
 
@@ -185,9 +231,13 @@ int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bo
     bool same = (nbatch == c->last_nbatch) && std::memcmp(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch) == 0;
     if (!same) {
         std::memcpy(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch);
-        // pageable source: the copy into the runtime's staging buffer is complete when the call returns
-        HIPCHK(c, hipMemcpyAsync(c->d_bslot, c->h_bslot.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));   // h_bslot may be rewritten by the next call
+        // the table travels through the pinned ring: no wait for the device (the lock-step optimiser changes the active set on
+        // most steps; stream order puts the copy behind the kernels of the previous call that still read the old table)
+        void *pin = nullptr;
+        int rcp = pin_stage(c, sizeof(int) * nbatch, &pin);
+        if (rcp) return rcp;
+        std::memcpy(pin, eff.data(), sizeof(int) * nbatch);
+        HIPCHK(c, hipMemcpyAsync(c->d_bslot, pin, sizeof(int) * nbatch, hipMemcpyHostToDevice, c->stream));
         c->last_nbatch = nbatch;
     }
     return MEDGP_OK;
@@ -220,7 +270,7 @@ int ensure_la(medgp_ctx *c, int nbatch, int nbmax, LaArgs *out) {
     const size_t need_small = (size_t)nbatch * (64 * (size_t)c->ldn + 4 * 4096 + 1);
     auto grow = [&](double **p, size_t *cap, size_t need) -> int {
         if (need <= *cap) return MEDGP_OK;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipDeviceSynchronize());   // the old scratch may still be read by kernels queued on any of the context's streams
         if (*p) {
             (void)hipFree(*p);
             c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), (void *)*p), c->allocs.end());
@@ -272,11 +322,14 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
     // 200: 6.0 vs 5.1; N=2048: 16: 4.4 vs 32, 64: 11.4 vs 33.5.  The multi-CU time grows linearly with the batch, the
     // single-workgroup time is flat up to one patient per CU: the crossover sits near 0.6 #CU for every N >= 512.
     const bool multi_cu = !c->use_v0 && (c->force_mc > 0 || (c->force_mc == 0 && nt64 >= 2 && nbatch <= (c->num_cu * 3) / 5));
+#ifdef MEDGP_LEGACY_AB
     if (c->use_v0) {
         launch_assemble();
         { Launcher l(c, KID_POTRF, stream); hipLaunchKernelGGL(k_potrf_v0, dim3(nbatch), dim3(256), 0, stream, L); }
         if (want_mode) { Launcher l(c, KID_TRTRI, stream); hipLaunchKernelGGL(k_trtri_v0, dim3(nbatch), dim3(256), 0, stream, L); }
-    } else if (multi_cu) {
+    } else
+#endif
+    if (multi_cu) {
         // The reference's retry loop (c_inference_exact.cpp:99-111: add the noise vector again, at most 10 times) is driven
         // from the host here: a failed pivot leaves status -2; the failed problems restart with one more noise addition
         // (L.jit), finished ones are recomputed identically (same inputs, same order of operations).
@@ -292,13 +345,16 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         if (!c->mc_old) { int rc = ensure_la(c, nbatch, nt64, &la); if (rc) return rc; }
         for (int attempt = 0;; attempt++) {
             launch_assemble();
+#ifdef MEDGP_LEGACY_AB
             if (c->mc_old) {
                 for (int k = 0; k < nt64; k++) {
                     { Launcher l(c, KID_CI_PANEL, stream); hipLaunchKernelGGL(k_ci_panel, dim3(nbatch, nt64), dim3(MC_THREADS), 0, stream, L, k, want_mode); }
                     if (nt64 > 1) { Launcher l(c, KID_CI_TRSM, stream); hipLaunchKernelGGL(k_ci_trsm, dim3(nt64 - 1, nbatch), dim3(MC_THREADS), 0, stream, L, k, want_mode); }
                 }
                 hipLaunchKernelGGL(k_ci_finish, dim3(nbatch), dim3(256), 0, stream, L);
-            } else {
+            } else
+#endif
+            {
                 // entries of a single 64-block: one workgroup each (the same kernel, hence the same bits, as in any other call)
                 if (any_small) { Launcher l(c, KID_CHOLINV, stream); hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, want_mode, 1); }
                 // look-ahead schedule: one launch per 64-wide step (kernels_cholinv_la.h)
@@ -420,7 +476,8 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
     c->last_has_inverse = flag_grad || need_inverse;
     std::vector<int> ens(nbatch);   // n of every entry (host mirror)
     for (int bb = 0; bb < nbatch; bb++) { const int es = c->h_bslot[bb]; ens[bb] = c->h_n[es >= c->max_slots ? es - c->max_slots : es]; }
-    const bool split = !c->use_v0 && c->nsplit >= 2 && nbatch >= 2 * c->num_cu && c->aux[0] && c->aux[1];
+    // (never together with the multi-CU schedule: its look-ahead scratch is one per-context buffer, not one per stream)
+    const bool split = !c->use_v0 && c->nsplit >= 2 && c->force_mc <= 0 && nbatch >= 2 * c->num_cu && c->aux[0] && c->aux[1];
     if (!split) return run_pipeline_one(c, c->stream, c->dev, nbatch, max_n, theta_dev, flag_grad, need_inverse, min_n, nlml_dev, grad_dev, status_dev, store_ukk, ens.data());
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     const int h = (nbatch / 2 + 1) & ~1;   // even: keeps the (b & 1) wave mirroring of k_cholinv consistent
@@ -474,14 +531,16 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
         return fail(nullptr, MEDGP_ERR_HIP, "cannot initialise device %d", device);
     }
     c->stream = c->own_stream;
+#ifdef MEDGP_LEGACY_AB   // first-generation kernels: A/B builds only (make LEGACY=1)
     { const char *e = getenv("MEDGP_V0"); c->use_v0 = e && e[0] == '1'; }
+    { const char *e = getenv("MEDGP_MC_OLD"); c->mc_old = e ? atoi(e) : 0; }
+#endif
     { const char *e = getenv("MEDGP_CHOLINV_NW"); c->cholinv_nw = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_LA_PARK"); if (e) c->la_park = atoi(e); }
     { const char *e = getenv("MEDGP_LA_PARK_MAXBATCH"); if (e) c->la_park_maxbatch = atoi(e); }
     { const char *e = getenv("MEDGP_MULTI_CU"); c->force_mc = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_STREAMS"); c->nsplit = e ? atoi(e) : 1; }
     { const char *e = getenv("MEDGP_DEBUG_FAIL_ATTEMPTS"); c->dbg_fail = e ? atoi(e) : 0; }
-    { const char *e = getenv("MEDGP_MC_OLD"); c->mc_old = e ? atoi(e) : 0; }
     for (int i = 0; i < 2; i++) {
         (void)hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
         (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
@@ -497,6 +556,7 @@ void medgp_destroy(medgp_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     free_all(c);
     for (int i = 0; i < 2; i++) {
         if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
@@ -506,6 +566,11 @@ void medgp_destroy(medgp_ctx *c) {
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_bounce) (void)hipHostFree(c->h_bounce);
+    for (int i = 0; i < 2; i++) {
+        if (c->pin_buf[i]) (void)hipHostFree(c->pin_buf[i]);
+        if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
+        if (c->ev_lane[i]) (void)hipEventDestroy(c->ev_lane[i]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -567,6 +632,12 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     if ((rc = dalloc(c, &c->d_nlml, B))) return rc;
     if ((rc = dalloc(c, &c->d_grad, B * H))) return rc;
     if ((rc = dalloc(c, &c->d_status_out, B))) return rc;
+    if ((rc = dalloc(c, &c->d_theta1, B * H))) return rc;
+    if ((rc = dalloc(c, &c->d_nlml1, B))) return rc;
+    if ((rc = dalloc(c, &c->d_grad1, B * H))) return rc;
+    if ((rc = dalloc(c, &c->d_status1, B))) return rc;
+    c->lane_pending[0] = c->lane_pending[1] = false;
+    c->d_prior_stage = nullptr; c->d_prior_slots = nullptr; c->prior_stage_rows = 0;   // freed by free_all above
     MedgpDev &L = c->dev;
     L.kidx = c->kidx; L.Q = c->Q; L.D = c->D; L.R = c->R; L.H = c->H; L.nlik = c->nlik;
     L.ldn = ldn; L.max_slots = max_slots; L.max_batch = max_batch;
@@ -630,8 +701,13 @@ int upload_patients(medgp_ctx *c, const std::vector<UpEntry> &ents) {
     const int D = c->D, S = c->max_slots, ldn = c->ldn;
     const bool use_meta = (c->kidx == MEDGP_KERNEL_LMC_SM);
     // validate everything before touching any state
+    std::vector<uint8_t> seen(ents.size() > 1 ? (size_t)S : 0, 0);
     for (const UpEntry &e : ents) {
         if (e.slot < 0 || e.slot >= S) return fail(c, MEDGP_ERR_CAPACITY, "slot %d outside [0, %d)", e.slot, S);
+        if (!seen.empty()) {   // two scatter workgroups would write the same rows, and the host mirrors would keep whichever came last
+            if (seen[e.slot]) return fail(c, MEDGP_ERR_ARG, "slot %d appears twice in one packed upload", e.slot);
+            seen[e.slot] = 1;
+        }
         if (e.n < 0 || e.n > c->max_n) return fail(c, MEDGP_ERR_CAPACITY, "n = %d outside [0, %d]", e.n, c->max_n);
         if (e.n > 0 && (!e.t || !e.y)) return fail(c, MEDGP_ERR_ARG, "t / y is NULL");
         if (use_meta && e.n > 0 && !e.meta) return fail(c, MEDGP_ERR_ARG, "meta is NULL for the multi-output kernel");
@@ -746,31 +822,70 @@ int medgp_set_patients(medgp_ctx *c, int nslots, const int32_t *slots, const int
     return upload_patients(c, ents);
 }
 
+namespace {
+// rows: nrows descriptors of H hypers each (flag == NULL: "no prior"); slots == NULL: ONE row for every slot of the context.
+// One pinned staging copy, one H2D transfer, one scatter kernel; nothing waits for the device.
+int upload_priors(medgp_ctx *c, int nrows, const int32_t *slots, const uint8_t *flag, const int32_t *type, const uint8_t *is_exp,
+                  const float *p0, const float *p1) {
+    const int H = c->H;
+    if (flag && (!type || !is_exp || !p0 || !p1)) return fail(c, MEDGP_ERR_ARG, "prior arrays must all be given");
+    for (int k = 0; slots && k < nrows; k++)
+        if (slots[k] < 0 || slots[k] >= c->max_slots) return fail(c, MEDGP_ERR_CAPACITY, "slot %d outside [0, %d)", slots[k], c->max_slots);
+    if (flag)
+        for (size_t h = 0; h < (size_t)nrows * H; h++)
+            if (type[h] < -1 || type[h] > 2) return fail(c, MEDGP_ERR_ARG, "prior type[%zu] = %d unsupported (KDE prior type 3 is never constructed by the reference's mains)", h, type[h]);
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((size_t)nrows > c->prior_stage_rows) {
+        HIPCHK(c, hipDeviceSynchronize());
+        for (void *q : {(void *)c->d_prior_stage, (void *)c->d_prior_slots})
+            if (q) { (void)hipFree(q); c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), q), c->allocs.end()); }
+        c->d_prior_stage = nullptr; c->d_prior_slots = nullptr; c->prior_stage_rows = 0;
+        const size_t rows = std::max<size_t>(nrows, 16);
+        int rc;
+        if ((rc = dalloc(c, &c->d_prior_stage, rows * H))) return rc;
+        if ((rc = dalloc(c, &c->d_prior_slots, rows))) return rc;
+        c->prior_stage_rows = rows;
+    }
+    const size_t row_bytes = sizeof(MedgpPrior) * (size_t)H, slot_bytes = ((sizeof(int) * (size_t)nrows) + 15) & ~(size_t)15;
+    void *pin = nullptr;
+    int rc = pin_stage(c, slot_bytes + row_bytes * nrows, &pin);
+    if (rc) return rc;
+    int *hs = (int *)pin;
+    MedgpPrior *hp = (MedgpPrior *)((char *)pin + slot_bytes);
+    for (int k = 0; k < nrows; k++) {
+        hs[k] = slots ? slots[k] : -1;
+        for (int h = 0; h < H; h++) {
+            MedgpPrior p{};
+            const size_t e = (size_t)k * H + h;
+            if (flag) { p.p0 = p0[e]; p.p1 = p1[e]; p.type = (int8_t)type[e]; p.flag = flag[e] ? 1 : 0; p.is_exp = is_exp[e] ? 1 : 0; }
+            else p.type = -1;
+            hp[e] = p;
+        }
+    }
+    if (slots) HIPCHK(c, hipMemcpyAsync(c->d_prior_slots, hs, sizeof(int) * nrows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_prior_stage, hp, row_bytes * nrows, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_scatter_priors, dim3(slots ? nrows : c->max_slots), dim3(256), 0, c->stream, (const MedgpPrior *)c->d_prior_stage,
+                       slots ? (const int *)c->d_prior_slots : (const int *)nullptr, H, c->d_prior, c->d_prior_on, (uint8_t)(flag ? 1 : 0));
+    HIPCHK(c, hipGetLastError());
+    return MEDGP_OK;
+}
+}  // namespace
+
 int medgp_set_prior(medgp_ctx *c, int slot, const uint8_t *flag, const int32_t *type, const uint8_t *is_exp,
                     const float *p0, const float *p1) {
     if (!c) return MEDGP_ERR_ARG;
     if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
     if (slot < -1 || slot >= c->max_slots) return fail(c, MEDGP_ERR_CAPACITY, "slot %d outside [-1, %d)", slot, c->max_slots);
-    if (flag && (!type || !is_exp || !p0 || !p1)) return fail(c, MEDGP_ERR_ARG, "prior arrays must all be given");
-    const int H = c->H;
-    std::vector<MedgpPrior> hp(H);
-    for (int h = 0; h < H; h++) {
-        MedgpPrior p{};
-        if (flag) {
-            if (type[h] < -1 || type[h] > 2) return fail(c, MEDGP_ERR_ARG, "prior type[%d] = %d unsupported (KDE prior type 3 is never constructed by the reference's mains)", h, type[h]);
-            p.p0 = p0[h]; p.p1 = p1[h]; p.type = (int8_t)type[h]; p.flag = flag[h] ? 1 : 0; p.is_exp = is_exp[h] ? 1 : 0;
-        } else { p.type = -1; }
-        hp[h] = p;
-    }
-    HIPCHK(c, hipSetDevice(c->device));
-    const uint8_t on = flag ? 1 : 0;
-    const int s0 = slot < 0 ? 0 : slot, s1 = slot < 0 ? c->max_slots : slot + 1;
-    for (int s = s0; s < s1; s++) {
-        HIPCHK(c, hipMemcpyAsync(c->d_prior + (size_t)s * H, hp.data(), sizeof(MedgpPrior) * H, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_prior_on + s, &on, 1, hipMemcpyHostToDevice, c->stream));
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return MEDGP_OK;
+    const int32_t s1 = slot;
+    return upload_priors(c, 1, slot < 0 ? nullptr : &s1, flag, type, is_exp, p0, p1);
+}
+
+int medgp_set_priors(medgp_ctx *c, int nslots, const int32_t *slots, const uint8_t *flag, const int32_t *type,
+                     const uint8_t *is_exp, const float *p0, const float *p1) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
+    if (nslots < 1 || !slots) return fail(c, MEDGP_ERR_ARG, "medgp_set_priors: bad argument");
+    return upload_priors(c, nslots, slots, flag, type, is_exp, p0, p1);
 }
 
 int medgp_nlml_grad_device(medgp_ctx *c, int nbatch, const int32_t *slots, const double *theta_dev, int flag_grad,
@@ -806,6 +921,48 @@ int medgp_nlml_grad(medgp_ctx *c, int nbatch, const int32_t *slots, const double
     if (flag_grad & MEDGP_FLAG_GRAD) HIPCHK(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * nbatch * H, hipMemcpyDeviceToHost, c->stream));
     if (status) HIPCHK(c, hipMemcpyAsync(status, c->d_status_out, sizeof(int32_t) * nbatch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MEDGP_OK;
+}
+
+void *medgp_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void medgp_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+int medgp_nlml_grad_async(medgp_ctx *c, int lane, int nbatch, const int32_t *slots, const double *theta, int flag_grad,
+                          double *nlml, double *grad, int32_t *status) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (lane < 0 || lane > 1) return fail(c, MEDGP_ERR_ARG, "lane %d outside {0, 1}", lane);
+    if (!slots || !theta || !nlml) return fail(c, MEDGP_ERR_ARG, "NULL argument");
+    if ((flag_grad & MEDGP_FLAG_GRAD) && !grad) return fail(c, MEDGP_ERR_ARG, "grad is NULL with flag_grad set");
+    if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
+    if (nbatch < 1 || nbatch > c->max_batch) return fail(c, MEDGP_ERR_CAPACITY, "nbatch %d outside [1, %d]", nbatch, c->max_batch);
+    if (c->lane_pending[lane]) return fail(c, MEDGP_ERR_ARG, "lane %d still holds a call: medgp_wait it first", lane);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t H = c->H;
+    double *dth = lane ? c->d_theta1 : c->d_theta, *dnl = lane ? c->d_nlml1 : c->d_nlml, *dgr = lane ? c->d_grad1 : c->d_grad;
+    int *dst = lane ? c->d_status1 : c->d_status_out;
+    HIPCHK(c, hipMemcpyAsync(dth, theta, sizeof(double) * nbatch * H, hipMemcpyHostToDevice, c->stream));
+    int rc = medgp_nlml_grad_device(c, nbatch, slots, dth, flag_grad, dnl, dgr, dst);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(nlml, dnl, sizeof(double) * nbatch, hipMemcpyDeviceToHost, c->stream));
+    if (flag_grad & MEDGP_FLAG_GRAD) HIPCHK(c, hipMemcpyAsync(grad, dgr, sizeof(double) * nbatch * H, hipMemcpyDeviceToHost, c->stream));
+    if (status) HIPCHK(c, hipMemcpyAsync(status, dst, sizeof(int32_t) * nbatch, hipMemcpyDeviceToHost, c->stream));
+    if (!c->ev_lane[lane]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_lane[lane], hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_lane[lane], c->stream));
+    c->lane_pending[lane] = true;
+    return MEDGP_OK;
+}
+
+int medgp_wait(medgp_ctx *c, int lane) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (lane < 0 || lane > 1) return fail(c, MEDGP_ERR_ARG, "lane %d outside {0, 1}", lane);
+    if (!c->lane_pending[lane]) return MEDGP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev_lane[lane]));
+    c->lane_pending[lane] = false;
     return MEDGP_OK;
 }
 
@@ -987,6 +1144,10 @@ int medgp_debug_read_xk(medgp_ctx *c, int b, void *out, int nbytes, int clear) {
 int medgp_profile_enable(medgp_ctx *c, int enable) {
     if (!c) return MEDGP_ERR_ARG;
     if (!enable && c->profiling) { int rc = drain_events(c); if (rc) return rc; }
+    if (enable) {   // warm the event pool outside any timed region (20 steps x 7 launches x 2 events of a default bench run)
+        HIPCHK(c, hipSetDevice(c->device));
+        while (c->ev_pool.size() < 512) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreate(&e)); c->ev_pool.push_back(e); }
+    }
     c->profiling = enable != 0;
     return MEDGP_OK;
 }
@@ -1077,6 +1238,11 @@ int medgp_kde_mode_at(int device, int nseries, const int64_t *off, const int32_t
         chk(hipMemcpy(status, d_st, sizeof(int) * nseries, hipMemcpyDeviceToHost), "hipMemcpy");
         if (bw) chk(hipMemcpy(bw, d_bw, sizeof(double) * nseries, hipMemcpyDeviceToHost), "hipMemcpy");
         if (kernel_ms && rc == MEDGP_OK) { float ms = 0.f; chk(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime"); *kernel_ms = ms; }
+        // a non-finite grid point makes the reference's arg-max / weighted mean NaN (np.argmax returns the NaN's index): report
+        // the series as failed instead of silently skipping the point
+        for (int s = 0; tcnt && rc == MEDGP_OK && s < nseries; s++)
+            for (int i = 0; i < tcnt[s]; i++)
+                if (!std::isfinite(test[toff[s] + i])) { status[s] = -1; mode[s] = std::nan(""); break; }
     }
     if (e0) hipEventDestroy(e0);
     if (e1) hipEventDestroy(e1);

@@ -7,7 +7,14 @@
 //     medgp_train --cfg exp_setup.json --pan-list pans.txt [--device d] [--max-batch B]
 // Outputs per patient (ref :257-323): train_init_hyp_<PAN>.bin, train_hyp_<PAN>.bin, train_var_hyp_<PAN>.bin
 // (prior mode 2), train_num_<PAN>.txt, train_flag_<PAN>.txt.
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <sstream>
+#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -46,19 +53,107 @@ struct Patient {
     bool use_vem = false, active = false;
 };
 
-bool upload_prior(medgp_ctx *ctx, Patient &p) {
-    vector<uint8_t> flag, ex;
-    vector<int32_t> type;
-    vector<float> p0, p1;
-    p.prior.flatten(flag, type, ex, p0, p1);
-    return medgp_set_prior(ctx, p.slot, flag.data(), type.data(), ex.data(), p0.data(), p1.data()) == 0;
+// host cores this process may use: hardware threads capped by the cgroup CPU quota (a box with many more hardware threads
+// than quota must not get one worker per hardware thread)
+int usable_cores() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    string q;
+    long long per = 0;
+    if (f >> q >> per && q != "max" && per > 0) n = std::min<long long>(n, std::max<long long>(1, atoll(q.c_str()) / per));
+    return std::max(1, std::min(n, 64));
+}
+
+// Persistent worker threads for the per-patient host work (file loading, optimiser state machines).  Workers BLOCK on a condition
+// variable between jobs -- no spinning (an OpenMP team's spinning workers starved the HIP runtime under the box's cgroup quota).
+class WorkPool {
+public:
+    explicit WorkPool(int nthreads) {
+        for (int i = 1; i < nthreads; i++) workers.emplace_back([this] { loop(); });
+    }
+    ~WorkPool() {
+        { std::lock_guard<std::mutex> l(m); stop = true; }
+        cv.notify_all();
+        for (auto &t : workers) t.join();
+    }
+    // fn(i) for i in [0, n), dynamically dealt in chunks; returns when all are done (the caller works too)
+    void parallel_for(int n, const std::function<void(int)> &fn) {
+        if (n <= 0) return;
+        if (workers.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+        {
+            std::lock_guard<std::mutex> l(m);
+            job = &fn; total = n; next.store(0); pending = (int)workers.size(); gen++;
+        }
+        cv.notify_all();
+        run();
+        std::unique_lock<std::mutex> l(m);
+        done_cv.wait(l, [this] { return pending == 0; });
+        job = nullptr;
+    }
+    int size() const { return (int)workers.size() + 1; }
+
+private:
+    void run() {
+        const int chunk = std::max(1, total / (8 * ((int)workers.size() + 1)));
+        while (true) {
+            const int i0 = next.fetch_add(chunk);
+            if (i0 >= total) break;
+            for (int i = i0; i < std::min(total, i0 + chunk); i++) (*job)(i);
+        }
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        while (true) {
+            {
+                std::unique_lock<std::mutex> l(m);
+                cv.wait(l, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+            }
+            run();
+            { std::lock_guard<std::mutex> l(m); pending--; }
+            done_cv.notify_one();
+        }
+    }
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv, done_cv;
+    const std::function<void(int)> *job = nullptr;
+    std::atomic<int> next{0};
+    int total = 0, pending = 0;
+    unsigned long long gen = 0;
+    bool stop = false;
+};
+
+// prior descriptors of several patients in ONE transfer (medgp_set_priors): every variational-EM outer iteration changes psi of
+// every patient that finished its sub-optimisation in this step (ref: util/c_optimizer_varEM.cpp:98-162)
+bool upload_priors(medgp_ctx *ctx, const vector<Patient *> &ps, int H, WorkPool &pool) {
+    if (ps.empty()) return true;
+    const size_t n = ps.size();
+    vector<int32_t> slots(n), type(n * H);
+    vector<uint8_t> flag(n * H), ex(n * H);
+    vector<float> p0(n * H), p1(n * H);
+    pool.parallel_for((int)n, [&](int k) {
+        vector<uint8_t> f, e;
+        vector<int32_t> t;
+        vector<float> a, b;
+        ps[k]->prior.flatten(f, t, e, a, b);
+        slots[k] = ps[k]->slot;
+        std::copy(f.begin(), f.end(), flag.begin() + (size_t)k * H);
+        std::copy(t.begin(), t.end(), type.begin() + (size_t)k * H);
+        std::copy(e.begin(), e.end(), ex.begin() + (size_t)k * H);
+        std::copy(a.begin(), a.end(), p0.begin() + (size_t)k * H);
+        std::copy(b.begin(), b.end(), p1.begin() + (size_t)k * H);
+    });
+    return medgp_set_priors(ctx, (int)n, slots.data(), flag.data(), type.data(), ex.data(), p0.data(), p1.data()) == 0;
 }
 
 }  // namespace
 
 int main(int argc, const char *argv[]) {
     string exp_cfg, pan_arg, pan_list;
-    int thread_num = 1, device = 0, max_batch = 1024;
+    int thread_num = 1, device = 0, max_batch = 1024, host_threads = 0, pingpong_min = 1024;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--cfg") && i + 1 < argc) exp_cfg = argv[++i];
         else if (!strcmp(argv[i], "--pan") && i + 1 < argc) pan_arg = argv[++i];
@@ -66,6 +161,8 @@ int main(int argc, const char *argv[]) {
         else if (!strcmp(argv[i], "--thread") && i + 1 < argc) thread_num = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--max-batch") && i + 1 < argc) max_batch = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--host-threads") && i + 1 < argc) host_threads = atoi(argv[++i]);   // 0 = usable cores (<= 16)
+        else if (!strcmp(argv[i], "--pingpong-min") && i + 1 < argc) pingpong_min = atoi(argv[++i]);   // active patients from which the lock-step loop splits them in two alternating halves
         else { cout << "Error: unknown argument: " << argv[i] << endl; return 1; }
     }
     if (exp_cfg.empty() || (pan_arg.empty() && pan_list.empty())) {
@@ -96,22 +193,37 @@ int main(int argc, const char *argv[]) {
     time_t t_start;
     time(&t_start);
 
-    // ---------------- load patients, data-quality check (ref :185-197)
-    vector<std::unique_ptr<Patient>> pts;
-    int max_n = 1;
-    for (const string &PAN : pans) {
+    // ---------------- load patients, data-quality check (ref :185-197).  The reference loads ONE patient per process
+    // (ref: dataio/c_experiment.cpp:254-309, D feature files each); a cohort is loaded by a pool of host threads over the
+    // patients, the log lines are printed afterwards in patient order, and the whole cohort goes to the device as ONE packed
+    // upload (medgp_set_patients: one transfer, one scatter kernel)
+    if (host_threads <= 0) host_threads = std::min(16, usable_cores());
+    WorkPool pool(std::max(1, host_threads));
+    const auto t_load0 = std::chrono::steady_clock::now();
+    vector<std::unique_ptr<Patient>> pts(pans.size());
+    vector<string> load_log(pans.size()), load_err(pans.size());
+    pool.parallel_for((int)pans.size(), [&](int i) {
+        c_experiment ex = curr_exp;                 // own error string per task
         std::unique_ptr<Patient> p(new Patient());
-        p->PAN = PAN;
-        cout << "running individual training..." << endl << "current patinet PAN = " << PAN << endl;
-        if (!curr_exp.get_one_patient_data(PAN, p->meta, p->t, p->y)) { cout << "ERROR: " << curr_exp.error() << endl; return 1; }
-        cout << "current number of data points = " << p->t.size() << endl;
-        vector<int> count_array(curr_exp.get_feature_index().size(), 0);
+        p->PAN = pans[i];
+        std::ostringstream os;
+        os << "running individual training..." << endl << "current patinet PAN = " << p->PAN << endl;
+        if (!ex.get_one_patient_data(p->PAN, p->meta, p->t, p->y)) { load_err[i] = ex.error(); pts[i] = std::move(p); return; }
+        os << "current number of data points = " << p->t.size() << endl;
+        vector<int> count_array(ex.get_feature_index().size(), 0);
         for (size_t k = 0; k < p->t.size(); k++) count_array[p->meta[k]] += 1;
         for (int c : count_array) if (c < 2) { p->sample_flag = false; break; }
-        if (!p->sample_flag) cout << "skip due to insufficient # of samples" << endl;
-        max_n = std::max(max_n, (int)p->t.size());
-        pts.push_back(std::move(p));
+        if (!p->sample_flag) os << "skip due to insufficient # of samples" << endl;
+        load_log[i] = os.str();
+        pts[i] = std::move(p);
+    });
+    int max_n = 1;
+    for (size_t i = 0; i < pans.size(); i++) {
+        cout << load_log[i];
+        if (!load_err[i].empty()) { cout << "ERROR: " << load_err[i] << endl; return 1; }
+        max_n = std::max(max_n, (int)pts[i]->t.size());
     }
+    const auto t_load1 = std::chrono::steady_clock::now();
 
     // ---------------- device context: every usable patient resident in its own slot
     vector<Patient *> live;
@@ -128,14 +240,29 @@ int main(int argc, const char *argv[]) {
             max_batch = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(std::max(1, max_batch), want), fit));
         }
         if (medgp_reserve(ctx, nslot, max_n, max_batch)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
-        for (size_t s = 0; s < live.size(); s++) {
-            Patient &p = *live[s];
-            p.slot = (int)s;
-            const int32_t *mp = (kidx == 7) ? (const int32_t *)p.meta.data() : nullptr;
-            if (medgp_set_patient(ctx, p.slot, (int)p.t.size(), mp, p.t.data(), p.y.data())) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
-            p.prior.initialize_param(curr_exp.get_cov_num(), curr_exp.get_mean_num(), curr_exp.get_lik_num());   // ref :222-226
+        // packed SoA cohort arrays (stacked meta / t / y with offsets)
+        vector<int32_t> slots(live.size());
+        vector<int64_t> offs(live.size() + 1, 0);
+        for (size_t s = 0; s < live.size(); s++) { live[s]->slot = (int)s; slots[s] = (int)s; offs[s + 1] = offs[s] + (int64_t)live[s]->t.size(); }
+        vector<int32_t> meta_all((size_t)offs.back());
+        vector<float> t_all((size_t)offs.back()), y_all((size_t)offs.back());
+        pool.parallel_for((int)live.size(), [&](int s) {
+            const Patient &p = *live[s];
+            std::copy(p.meta.begin(), p.meta.end(), meta_all.begin() + offs[s]);
+            std::copy(p.t.begin(), p.t.end(), t_all.begin() + offs[s]);
+            std::copy(p.y.begin(), p.y.end(), y_all.begin() + offs[s]);
+        });
+        if (medgp_set_patients(ctx, (int)live.size(), slots.data(), offs.data(), kidx == 7 ? meta_all.data() : nullptr, t_all.data(), y_all.data())) {
+            cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1;
         }
+        for (Patient *p : live) p->prior.initialize_param(curr_exp.get_cov_num(), curr_exp.get_mean_num(), curr_exp.get_lik_num());   // ref :222-226
         cout << "finish initialization of prior" << endl;
+    }
+    {
+        const auto t_up = std::chrono::steady_clock::now();
+        cout << "INFO: loaded " << pans.size() << " patients x " << curr_exp.get_feature_index().size() << " feature files in "
+             << std::chrono::duration<double>(t_load1 - t_load0).count() << " s on " << pool.size() << " host threads; packed upload "
+             << std::chrono::duration<double>(t_up - t_load1).count() << " s" << endl;
     }
 
     // ---------------- HOT LOOP A: random-init screening, nlml only (ref :228-253), batched over (patient, init)
@@ -181,64 +308,121 @@ int main(int argc, const char *argv[]) {
 
     // ---------------- HOT LOOP B: optimisation in lock step (ref :260-292)
     vector<Patient *> running;
+    const bool verbose = live.size() == 1;   // the per-iteration lines of one patient; a cohort's state machines run on host threads
     for (Patient *p : live) {
         if (!p->success) continue;
         p->prior.setup_param(kidx, kparam, curr_exp.get_prior_mode(), curr_exp.get_prior_hyp());
-        if (!upload_prior(ctx, *p)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
         p->use_vem = curr_exp.get_prior_mode() == 2;
-        if (p->use_vem) p->vem.start((-1) * curr_exp.get_scg_max_iter_num(), p->best_init, &p->prior, kparam, curr_exp.get_lik_num(), curr_exp.get_prior_sub_opt_iter(), true);
+        if (p->use_vem) p->vem.start((-1) * curr_exp.get_scg_max_iter_num(), p->best_init, &p->prior, kparam, curr_exp.get_lik_num(), curr_exp.get_prior_sub_opt_iter(), verbose);
         else p->scg.start((-1) * curr_exp.get_scg_max_iter_num(), p->best_init);
         p->active = p->use_vem ? !p->vem.done() : !p->scg.done();
         running.push_back(p);
     }
+    if (ctx && !upload_priors(ctx, running, H, pool)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
     cout << "start doing optimization" << endl;
     long long total_evals = 0, steps = 0;
-    double t_dev = 0.0, t_host = 0.0;   // seconds inside medgp_nlml_grad / in the optimiser state machines (incl. prior uploads)
+    double t_wait = 0.0, t_host = 0.0;   // seconds blocked in medgp_wait / in the optimiser state machines (incl. request copies, prior uploads)
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    while (true) {
+    const auto t_loop0 = now();
+    // Groups of patients that advance together: each group's step is one batched evaluation on one of the two asynchronous lanes
+    // of the context (medgp_nlml_grad_async); while the device works on one group the host threads run the state machines of the
+    // other (ref: the strictly sequential objective calls of util/c_optimizer_scg.cpp:65,120,221).  One group (no overlap, the
+    // whole active set in one launch -- the most efficient use of the device) unless the active set is large enough that each
+    // half still fills the chip (--pingpong-min) or exceeds max_batch.
+    struct Group { vector<Patient *> mem; double *th = nullptr, *nl = nullptr, *gr = nullptr; int32_t *st = nullptr; vector<int32_t> slots; int nb = 0; };
+    vector<Group> groups;
+    {
         vector<Patient *> act;
         for (Patient *p : running) if (p->active) act.push_back(p);
-        if (act.empty()) break;
-        for (size_t c0 = 0; c0 < act.size(); c0 += max_batch) {
-            const int nb = (int)std::min<size_t>(max_batch, act.size() - c0);
-            const auto t0 = now();
-            vector<int32_t> slots(nb), st(nb);
-            vector<double> thetas((size_t)nb * H), nl(nb), gr((size_t)nb * H);
-            for (int k = 0; k < nb; k++) {
-                Patient *p = act[c0 + k];
-                slots[k] = p->slot;
-                const vector<double> &rq = p->use_vem ? p->vem.request() : p->scg.request();
-                std::copy(rq.begin(), rq.end(), thetas.begin() + (size_t)k * H);
-            }
-            const auto t1 = now();
-            if (medgp_nlml_grad(ctx, nb, slots.data(), thetas.data(), 1, nl.data(), gr.data(), st.data())) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
-            const auto t2 = now();
-            total_evals += nb;
-            // (the state machines are independent and were tried under `#pragma omp parallel for`: on the GPU box -- a 16-core cgroup
-            //  quota on a host with many more hardware threads -- libgomp's default team and its spinning workers starved the HIP
-            //  runtime: 0.065 -> 10.4 s of host time and 0.15 -> 1.2 s inside medgp_nlml_grad for 94 steps of 256 patients.  The
-            //  serial loop is 30 % of the optimisation loop's wall time, 9 % of the whole run: left serial.)
-            for (int k = 0; k < nb; k++) {
-                Patient *p = act[c0 + k];
-                vector<double> g(gr.begin() + (size_t)k * H, gr.begin() + (size_t)(k + 1) * H);
-                const bool ok = st[k] >= 0;
-                if (p->use_vem) {
-                    p->vem.feed(ok, nl[k], g);
-                    if (p->vem.prior_changed() && !upload_prior(ctx, *p)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
-                    p->active = !p->vem.done();
-                } else {
-                    p->scg.feed(ok, nl[k], g);
-                    p->active = !p->scg.done();
-                }
-            }
-            t_dev += secs(t1, t2);
-            t_host += secs(t0, t1) + secs(t2, now());
+        int G = (int)((act.size() + max_batch - 1) / std::max(1, max_batch));
+        if ((int)act.size() >= 2 * std::max(1, pingpong_min)) G = std::max(G, 2);
+        G = std::max(G, 1);
+        const size_t per = (act.size() + G - 1) / std::max(G, 1);
+        for (int g = 0; g < G; g++) {
+            Group gp;
+            for (size_t k = g * per; k < std::min(act.size(), (g + 1) * per); k++) gp.mem.push_back(act[k]);
+            if (gp.mem.empty()) continue;
+            const size_t cap = gp.mem.size();
+            gp.th = (double *)medgp_host_alloc(sizeof(double) * cap * H);
+            gp.nl = (double *)medgp_host_alloc(sizeof(double) * cap);
+            gp.gr = (double *)medgp_host_alloc(sizeof(double) * cap * H);
+            gp.st = (int32_t *)medgp_host_alloc(sizeof(int32_t) * cap);
+            if (!gp.th || !gp.nl || !gp.gr || !gp.st) { cout << "ERROR: pinned host allocation failed" << endl; return 1; }
+            groups.push_back(std::move(gp));
         }
-        steps++;
     }
+    auto submit = [&](Group &g, int lane) -> bool {   // copy the requests of the group's active patients and queue the evaluation
+        vector<Patient *> act;
+        for (Patient *p : g.mem) if (p->active) act.push_back(p);
+        g.mem.swap(act);
+        g.nb = (int)g.mem.size();
+        if (g.nb == 0) return true;
+        g.slots.resize(g.nb);
+        pool.parallel_for(g.nb, [&](int k) {
+            Patient *p = g.mem[k];
+            g.slots[k] = p->slot;
+            const vector<double> &rq = p->use_vem ? p->vem.request() : p->scg.request();
+            std::copy(rq.begin(), rq.end(), g.th + (size_t)k * H);
+        });
+        if (medgp_nlml_grad_async(ctx, lane, g.nb, g.slots.data(), g.th, 1, g.nl, g.gr, g.st)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
+        total_evals += g.nb;
+        return true;
+    };
+    auto feed = [&](Group &g) -> bool {
+        vector<uint8_t> dirty(g.nb, 0);
+        pool.parallel_for(g.nb, [&](int k) {
+            Patient *p = g.mem[k];
+            vector<double> gk(g.gr + (size_t)k * H, g.gr + (size_t)(k + 1) * H);
+            const bool ok = g.st[k] >= 0;
+            if (p->use_vem) {
+                p->vem.feed(ok, g.nl[k], gk);
+                dirty[k] = p->vem.prior_changed() ? 1 : 0;
+                p->active = !p->vem.done();
+            } else {
+                p->scg.feed(ok, g.nl[k], gk);
+                p->active = !p->scg.done();
+            }
+        });
+        vector<Patient *> ch;
+        for (int k = 0; k < g.nb; k++) if (dirty[k]) ch.push_back(g.mem[k]);
+        if (!upload_priors(ctx, ch, H, pool)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
+        return true;
+    };
+    {
+        std::deque<std::pair<int, int>> inflight;   // (group, lane), oldest first
+        std::deque<int> ready;
+        for (int g = 0; g < (int)groups.size(); g++) ready.push_back(g);
+        int free_lanes[2] = {1, 1};
+        while (!ready.empty() || !inflight.empty()) {
+            while (!ready.empty() && (free_lanes[0] || free_lanes[1])) {
+                const int g = ready.front(); ready.pop_front();
+                const int lane = free_lanes[0] ? 0 : 1;
+                const auto t0 = now();
+                if (!submit(groups[g], lane)) return 1;
+                t_host += secs(t0, now());
+                if (groups[g].nb == 0) continue;          // every patient of the group is done
+                free_lanes[lane] = 0;
+                inflight.push_back({g, lane});
+                steps++;
+            }
+            if (inflight.empty()) break;
+            const auto pr = inflight.front(); inflight.pop_front();
+            const auto t1 = now();
+            if (medgp_wait(ctx, pr.second)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
+            const auto t2 = now();
+            if (!feed(groups[pr.first])) return 1;
+            t_wait += secs(t1, t2);
+            t_host += secs(t2, now());
+            free_lanes[pr.second] = 1;
+            ready.push_back(pr.first);
+        }
+        for (Group &g : groups) { medgp_host_free(g.th); medgp_host_free(g.nl); medgp_host_free(g.gr); medgp_host_free(g.st); }
+    }
+    const double t_loop = secs(t_loop0, now());
     cout << "optimization finished: " << total_evals << " nlml+grad evaluations in " << steps << " lock-step batches" << endl;
-    cout << "INFO: lock-step optimisation: " << t_dev << " s in medgp_nlml_grad, " << t_host << " s in the host optimiser" << endl;
+    cout << "INFO: lock-step optimisation: " << t_loop << " s wall (" << t_wait << " s waiting for the device, " << t_host
+         << " s in the host optimiser on " << pool.size() << " threads, " << groups.size() << " group(s))" << endl;
 
     // ---------------- outputs (ref :297-323)
     for (auto &pp : pts) {

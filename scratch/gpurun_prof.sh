@@ -1,7 +1,7 @@
 #!/bin/bash
 # profile run on the GPU box: kernel trace + PMC passes (each in its own run, as the guide prescribes)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 python3 bench.py --no-cpu-baseline --no-extra > gpurun_out/bench_${TAG}_plain.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > gpurun_out/bench_${TAG}_trace.log 2>&1
 grep '^{' gpurun_out/bench_${TAG}_trace.log | cut -c1-400

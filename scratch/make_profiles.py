@@ -4,13 +4,28 @@ sources the passes were taken from (bench.py refuses a stale traffic figure)."""
 import csv, glob, collections, json, os, shutil, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 shutil.copy(glob.glob(f'gpurun_out/prof_{tag}_trace/runc/*_kernel_stats.csv')[0], f'profiles/{rnd}_kernel_stats.csv')
 open(f'profiles/{rnd}_bench_line_under_rocprof.json', 'w').write([l for l in open(f'gpurun_out/bench_{tag}_trace.log') if l.startswith('{')][-1])
 try:
     open(f'profiles/{rnd}_bench_line.json', 'w').write([l for l in open(f'gpurun_out/bench_{tag}_plain.log') if l.startswith('{')][-1])
 except OSError:
     pass
+# steady-state per-kernel durations from the kernel trace itself: the --stats summary averages the cold launches in (round 2: max
+# 1.65 ms vs min 1.36 ms for k_cholinv), so the warm-up launches of every kernel are dropped here and the median is reported too
+WARM = int(os.environ.get("PROFILE_WARMUP_LAUNCHES", "3"))   # = --warmup of the traced bench command (scratch/gpurun_prof.sh)
+tr = glob.glob(f'gpurun_out/prof_{tag}_trace/runc/*_kernel_trace.csv')
+if tr:
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(tr[0])):
+        per[r['Kernel_Name']].append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+    with open(f'profiles/{rnd}_kernel_steady.csv', 'w') as f:
+        f.write(f'"Name","LaunchesUsed","WarmupDropped","MedianNs","MeanNs","MinNs","MaxNs"\n')
+        for k, v in sorted(per.items(), key=lambda kv: -sum(d for _, d in kv[1])):
+            v.sort()
+            d = [x[1] for x in v[min(WARM, max(len(v) - 1, 0)):]]
+            d.sort()
+            f.write(f'"{k}",{len(d)},{len(v) - len(d)},{d[len(d) // 2]},{sum(d) / len(d):.1f},{d[0]},{d[-1]}\n')
 out = {}
 for t in ('fetch', 'write', 'mfma', 'sq'):
     p = glob.glob(f'gpurun_out/prof_{tag}_{t}/runc/*_counter_collection.csv')[0]
@@ -45,3 +60,5 @@ for k, v in out.items():
     if k == '_meta': continue
     print(k, {a: (round(b, 3) if isinstance(b, float) and b < 10 else int(b)) for a, b in v.get('derived', {}).items()})
 print(open(f'profiles/{rnd}_kernel_stats.csv').read()[:1100])
+if tr:
+    print(open(f'profiles/{rnd}_kernel_steady.csv').read()[:1100])

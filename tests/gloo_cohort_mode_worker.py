@@ -31,6 +31,27 @@ def main():
     grids = [None, np.linspace(-3, 3, 50), None, np.linspace(-1, 1, 7), None, None, np.linspace(0, 2, 11)]
     m = cohort_mode.kde_modes(series, False, oracle_fn, tests=grids)
     assert np.array_equal(m, oracle_fn(series, False, grids))
+    # a series only ONE rank owns fails (the reference's KDE fit raises on it): every rank must raise -- nobody may be left
+    # waiting in the all_gather (round-2 advisor finding)
+    from medgp_amd import capi
+
+    def failing_fn(ss, w, tt=None):
+        if any(len(x) < 2 for x in ss):
+            raise capi.MedgpError("KDE fit failed for a series with fewer than two samples")
+        return oracle_fn(ss, w, tt)
+    bad = [rng.normal(size=n) for n in (30, 25, 1, 28)]            # the 1-sample series is dealt to exactly one rank
+    owner = cohort_mode.deal_series([len(x) * 2 * len(x) for x in bad], dist.get_world_size())
+    raised = False
+    try:
+        cohort_mode.kde_modes(bad, True, failing_fn)
+    except capi.MedgpError as e:
+        raised = True
+        mine = owner[2] == rank
+        assert ("fewer than two" in str(e)) == bool(mine), (rank, str(e))
+    assert raised
+    # and the group is still usable afterwards
+    m = cohort_mode.kde_modes(series, True, oracle_fn)
+    assert np.array_equal(m, oracle_fn(series, True))
     dist.barrier()
     if rank == 0:
         assert os.path.exists(os.path.join(out_dir, "all", "kmeans_mode_param.bin"))

@@ -1,0 +1,145 @@
+"""GPU tests of the host-overlap surface added in round 3: batched prior upload (medgp_set_priors), the two-lane asynchronous
+operator (medgp_nlml_grad_async / medgp_wait on pinned memory), slot tables that change on every call without a device wait,
+and the argument checks of the packed uploads.  Reference callers: util/c_optimizer_scg.cpp:65,120,221 (one objective call per
+line-search point), util/c_optimizer_varEM.cpp:98-162 (prior parameters change once per outer iteration)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import medgp_amd
+from medgp_amd import capi, synth
+
+
+def _ctx(P=12, D=3, N=70, Q=3, R=2, max_batch=None):
+    pts, th = synth.cohort(77, P, D, N, Q=Q, R=R)
+    ctx = medgp_amd.Context(7, Q, D, R)
+    ctx.reserve(P, N, max_batch or P)
+    ctx.set_patients(np.arange(P), pts)
+    return ctx, pts, th
+
+
+def test_set_priors_batched_equals_per_slot():
+    P, D, Q, R = 12, 3, 3, 2
+    ctx, pts, th = _ctx(P, D, 70, Q, R)
+    H = ctx.H
+    rng = np.random.default_rng(5)
+    f, ty, ex, p0, p1 = synth.hier_gamma_prior(Q, D, R, 0.01)
+    rows = []
+    for s in range(P):
+        q1 = p1.copy()
+        q1[D:D + Q * D * R] = rng.uniform(0.2, 3.0, Q * D * R).astype(np.float32)   # per-patient psi, as varEM produces them
+        t2 = ty.copy()
+        t2[D + rng.integers(0, Q * D * R, 3)] = 0                                    # a few clamped entries
+        rows.append((f, t2, ex, p0, q1))
+    for s in range(P):
+        ctx.set_prior(s, *rows[s])
+    ref = ctx.nlml_grad(np.arange(P), th, True)
+    ctx.set_prior(-1)                                   # remove everywhere (one broadcast row)
+    none = ctx.nlml_grad(np.arange(P), th, True)
+    assert not np.array_equal(none[0], ref[0])
+    order = rng.permutation(P)
+    ctx.set_priors(order, *[np.stack([rows[s][k] for s in order]) for k in range(5)])
+    got = ctx.nlml_grad(np.arange(P), th, True)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    ctx.set_priors(np.array([3, 4]))                    # flag == NULL: prior off for those two
+    part = ctx.nlml_grad(np.arange(P), th, True)
+    assert np.array_equal(part[0][[3, 4]], none[0][[3, 4]]) and np.array_equal(part[0][[0, 1, 2]], ref[0][[0, 1, 2]])
+    ctx.set_prior(-1, f, ty, ex, p0, p1)                # one row for every slot
+    allp = ctx.nlml_grad(np.arange(P), th, True)
+    for s in range(P):
+        ctx.set_prior(s, f, ty, ex, p0, p1)
+    allq = ctx.nlml_grad(np.arange(P), th, True)
+    assert np.array_equal(allp[0], allq[0]) and np.array_equal(allp[1], allq[1])
+    with pytest.raises(capi.MedgpError):
+        ctx.set_priors(np.array([0, P]), *[np.stack([rows[0][k]] * 2) for k in range(5)])
+    bad = rows[0][1].copy()
+    bad[0] = 3
+    with pytest.raises(capi.MedgpError):
+        ctx.set_priors(np.array([0]), rows[0][0][None], bad[None], rows[0][2][None], rows[0][3][None], rows[0][4][None])
+    ctx.close()
+
+
+def test_async_lanes_equal_synchronous_calls():
+    P = 12
+    ctx, pts, th = _ctx(P)
+    H = ctx.H
+    ref = ctx.nlml_grad(np.arange(P), th, True)
+    ref0 = ctx.nlml_grad(np.arange(P), th, False)
+    halves = [np.arange(0, 7), np.arange(7, P)]
+    bufs = []
+    for lane, idx in enumerate(halves):
+        n = idx.size
+        b = dict(th=ctx.pinned((n, H), np.float64), nl=ctx.pinned((n,), np.float64), gr=ctx.pinned((n, H), np.float64),
+                 st=ctx.pinned((n,), np.int32))
+        b["th"][:] = th[idx]
+        b["gr"][:] = -7.0
+        bufs.append(b)
+    for rep in range(3):      # both lanes in flight, different slot tables back to back (no device wait in between)
+        for lane, idx in enumerate(halves):
+            ctx.nlml_grad_async(lane, idx, bufs[lane]["th"], True, bufs[lane]["nl"], bufs[lane]["gr"], bufs[lane]["st"])
+        with pytest.raises(capi.MedgpError):          # a lane holds one call at a time
+            ctx.nlml_grad_async(0, halves[0], bufs[0]["th"], True, bufs[0]["nl"], bufs[0]["gr"], bufs[0]["st"])
+        for lane, idx in enumerate(halves):
+            ctx.wait(lane)
+            assert np.array_equal(bufs[lane]["nl"], ref[0][idx]) and np.array_equal(bufs[lane]["gr"], ref[1][idx])
+            assert np.array_equal(bufs[lane]["st"], ref[2][idx])
+    # nlml-only on a lane, pageable memory (allowed: the copies are then synchronous)
+    nl = np.empty(5)
+    st = np.empty(5, np.int32)
+    ctx.nlml_grad_async(1, np.arange(5), np.ascontiguousarray(th[:5]), False, nl, None, st)
+    ctx.wait(1)
+    assert np.array_equal(nl, ref0[0][:5])
+    ctx.wait(0)   # nothing pending: no-op
+    ctx.close()
+
+
+def test_slot_table_changes_every_call_without_sync():
+    """The lock-step optimiser shrinks / reorders its active set on most steps: many calls with different slot lists queued
+    back to back must each see their own table (it travels through a pinned ring, stream ordered)."""
+    import torch
+    P = 12
+    ctx, pts, th = _ctx(P)
+    H = ctx.H
+    ref = ctx.nlml_grad(np.arange(P), th, True)
+    dev = torch.device("cuda", 0)
+    th_d = torch.from_numpy(th).to(dev)
+    rng = np.random.default_rng(9)
+    outs = []
+    for it in range(40):
+        k = int(rng.integers(1, P + 1))
+        idx = rng.permutation(P)[:k]
+        t_in = th_d[torch.from_numpy(idx).to(dev)].contiguous()
+        nl = torch.empty(k, dtype=torch.float64, device=dev)
+        gr = torch.empty((k, H), dtype=torch.float64, device=dev)
+        st = torch.empty(k, dtype=torch.int32, device=dev)
+        ctx.nlml_grad_device(idx, t_in.data_ptr(), 1, nl.data_ptr(), gr.data_ptr(), st.data_ptr())
+        outs.append((idx, t_in, nl, gr, st))
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    for idx, _, nl, gr, st in outs:
+        assert np.array_equal(nl.cpu().numpy(), ref[0][idx]) and np.array_equal(gr.cpu().numpy(), ref[1][idx])
+    ctx.close()
+
+
+def test_packed_upload_rejects_duplicate_slots():
+    ctx, pts, th = _ctx(4)
+    with pytest.raises(capi.MedgpError) as e:
+        ctx.set_patients(np.array([1, 2, 1]), [pts[0], pts[1], pts[2]])
+    assert "twice" in str(e.value)
+    nl = ctx.nlml_grad(np.arange(4), th, False)[0]          # nothing was touched by the rejected call
+    ctx.set_patients(np.array([1, 2]), [pts[1], pts[2]])
+    assert np.array_equal(ctx.nlml_grad(np.arange(4), th, False)[0], nl)
+    ctx.close()
+
+
+def test_kde_grid_with_non_finite_point_is_reported():
+    rng = np.random.default_rng(3)
+    x = [rng.normal(size=200), rng.normal(size=150)]
+    grid = [np.linspace(-3, 3, 50), np.linspace(-3, 3, 40)]
+    ok = capi.kde_mode(x, False, 0, full=True, test=grid)
+    assert np.all(ok[2] == 0)
+    grid[1] = grid[1].copy()
+    grid[1][7] = np.nan
+    mode, bw, st, _ = capi.kde_mode(x, False, 0, full=True, test=grid)
+    assert st[0] == 0 and mode[0] == ok[0][0] and st[1] == -1 and np.isnan(mode[1])

@@ -1,0 +1,64 @@
+"""bench.py's multi-rank path on ONE GPU box: two ranks launched exactly as the driver launches them
+(python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 ...); with fewer GPUs than ranks the
+ranks share device 0 and the process group is gloo (bench.py's fallback), so everything except RCCL itself is exercised:
+sharding (weak and strong / LPT), max-over-ranks timing, whole-job value, ranks_seen, and -- the property that makes patient
+sharding legitimate -- per-patient results identical to the single-rank run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--steps", "2", "--warmup", "1", "--n", "128", "--no-extra", "--no-cpu-baseline"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, extra, dump):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world)]
+    r = subprocess.run(cmd + COMMON + extra + ["--dump-results", dump], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # ONE JSON line, from rank 0
+    res = {}
+    for k in range(world):
+        d = np.load(f"{dump}.rank{k}.npz")
+        for g, nl, gs, st in zip(d["gids"], d["nlml"], d["gsum"], d["status"]):
+            assert int(g) not in res
+            res[int(g)] = (nl, gs, int(st))
+    return json.loads(lines[0]), res
+
+
+@pytest.mark.parametrize("mode", ["weak", "strong"])
+def test_two_ranks_on_one_gpu_match_one_rank(tmp_path, mode):
+    if mode == "weak":
+        one, r1 = _run(1, ["--patients", "48"], str(tmp_path / "one"))
+        two, r2 = _run(2, ["--patients", "24"], str(tmp_path / "two"))
+    else:
+        one, r1 = _run(1, ["--scaling", "strong", "--cohort", "50"], str(tmp_path / "one"))
+        two, r2 = _run(2, ["--scaling", "strong", "--cohort", "50"], str(tmp_path / "two"))
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == mode
+    assert np.isfinite(two["value"]) and two["value"] > 0 and two["unit"] == "evals/s"
+    assert [r["rank"] for r in two["ranks_seen"]] == [0, 1] and two["backend"] in ("gloo", "nccl")
+    assert sum(r["patients"] for r in two["ranks_seen"]) == two["config"]["cohort"] == len(r2) == len(r1)
+    # value = whole-job units / max-over-ranks time
+    assert abs(two["value"] - two["config"]["cohort"] * two["steps"] / (two["ms_per_step"] * 1e-3 * two["steps"])) <= 1e-6 * two["value"]
+    assert sorted(r1) == sorted(r2)
+    for g in r1:
+        assert r1[g][2] == r2[g][2] == 0
+        assert r1[g][0] == r2[g][0] and r1[g][1] == r2[g][1], (g, r1[g], r2[g])   # same bits whichever rank / batch evaluated the patient

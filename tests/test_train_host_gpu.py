@@ -151,3 +151,31 @@ def test_train_vs_reference_optimiser_restatement(tmp_path, built_lib, prior_ind
         err = np.abs(got - np.array(theta)) / np.maximum(1.0, np.abs(theta))
         print(pan, "theta max err", float(err.max()), "evaluations", nev[0])
         assert err.max() <= 1e-6, (pan, float(err.max()))
+
+
+@pytest.mark.parametrize("prior_index", [2, 0])
+def test_train_pingpong_groups_and_host_threads_change_nothing(tmp_path, built_lib, prior_index):
+    """The lock-step loop may split the active set into alternating groups (two asynchronous lanes: the host threads run one
+    group's state machines while the device evaluates the other) and run the state machines on any number of host threads:
+    every patient's files are byte-identical to the one-group, one-thread run (patients are independent; ragged sizes, one
+    patient that finishes early through its evaluation budget)."""
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", HOST, "medgp_train"])
+    pans = [f"P{k:03d}" for k in range(7)]
+    Ns = [60, 75, 48, 52, 64, 33, 70]
+    exs = []
+    for tag, extra in (("a", ["--host-threads", "1", "--pingpong-min", "1000000"]), ("b", ["--host-threads", "4", "--pingpong-min", "2"]),
+                       ("c", ["--host-threads", "3", "--pingpong-min", "1000000", "--max-batch", "3"])):
+        ex = make_experiment(tmp_path / tag, pans, D=2, Q=3, R=2, N=Ns, prior_index=prior_index)
+        plist = tmp_path / f"pans_{tag}.txt"
+        plist.write_text("\n".join(pans) + "\n")
+        out = run(["--cfg", ex["cfg"], "--pan-list", str(plist)] + extra)
+        assert "lock-step batches" in out
+        exs.append((ex, out))
+    assert "1 group(s)" in exs[0][1] and "2 group(s)" in exs[1][1] and "3 group(s)" in exs[2][1]
+    for pan in pans:
+        for name in ["train_init_hyp_", "train_hyp_"] + (["train_var_hyp_"] if prior_index == 2 else []):
+            a = np.fromfile(os.path.join(exs[0][0]["dirs"]["train"], name + pan + ".bin"), np.float64)
+            for ex, _ in exs[1:]:
+                b = np.fromfile(os.path.join(ex["dirs"]["train"], name + pan + ".bin"), np.float64)
+                assert a.size > 0 and np.array_equal(a, b), (name, pan)
