@@ -277,7 +277,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--patients", type=int, default=512, help="patients per GPU")
-    ap.add_argument("--n", type=int, default=512)
+    ap.add_argument("--n", "--obs", dest="n", type=int, default=512, help="observations per patient (--obs: spelling that survives torch.distributed.run's prefix matching)")
     ap.add_argument("--D", type=int, default=24)
     ap.add_argument("--Q", type=int, default=5)
     ap.add_argument("--R", type=int, default=8)
@@ -372,7 +372,7 @@ def main():
     nl = nlml_d.cpu().numpy()
     assert np.all(st >= 0) and np.all(np.isfinite(nl)), "evaluation failed inside the timed region"
     if args.dump_results:
-        np.savez(f"{args.dump_results}.rank{rank}.npz", gids=gids, nlml=nl, gsum=grad_d.sum(dim=1).cpu().numpy(), status=st)
+        np.savez(f"{args.dump_results}.rank{rank}.npz", gids=gids, nlml=nl, gsum=grad_d.cpu().numpy().sum(axis=1), status=st)
     # who actually ran: (rank, device index, device name, uuid, host) of every rank, gathered once outside the timed region
     props = torch.cuda.get_device_properties(local_rank)
     me = {"rank": rank, "device": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")),

@@ -127,11 +127,11 @@ int medgp_nlml_grad(medgp_ctx *ctx, int nbatch, const int32_t *slots, const doub
                     double *nlml, double *grad, int32_t *status);
 
 /* Same operator with theta / nlml / grad / status in DEVICE memory of ctx's device, queued on the context's stream
- * (slots stays a host array: it only selects resident patients).  Asynchronous when every entry is factored by the
- * one-workgroup-per-patient kernel (more than 0.6 x #CU entries, or every n <= 64).  With fewer, larger entries the
- * multi-CU schedule is used and the call reads the per-entry factorisation status back ONCE before it returns (the
- * reference's jitter loop, ref: inference/c_inference_exact.cpp:99-111, is driven from the host there): the results are
- * still produced on the stream, but the call itself waits for the factorisation. */
+ * (slots stays a host array: it only selects resident patients; it is copied before the call returns).  Asynchronous for
+ * EVERY route: the one-workgroup-per-patient kernel runs the reference's jitter loop (ref: inference/c_inference_exact.cpp:
+ * 99-111) in-kernel, and the multi-CU schedule used for few, large entries (at most 0.6 x #CU entries with n > 64) hands the
+ * entries whose single attempt failed to that same in-kernel loop on the device (k_cholinv, sel = 2) -- the host reads no
+ * status back.  (Only growing the multi-CU scratch for a larger batch / n than any call before waits for the device once.) */
 int medgp_nlml_grad_device(medgp_ctx *ctx, int nbatch, const int32_t *slots, const double *theta_dev,
                            int flag_grad, double *nlml_dev, double *grad_dev, int32_t *status_dev);
 
@@ -140,8 +140,7 @@ int medgp_nlml_grad_device(medgp_ctx *ctx, int nbatch, const int32_t *slots, con
  * theta upload, the evaluation and the result downloads of `lane` (0 or 1; each lane has its own device staging) on the context's
  * stream and returns; medgp_wait(ctx, lane) blocks until that lane's results are in nlml / grad / status.  The host arrays must
  * stay valid (and untouched) until then, and overlap needs them in pinned memory: medgp_host_alloc / medgp_host_free
- * (hipHostMalloc; pageable memory works but makes the copies synchronous).  A lane holds one call at a time.  Calls that take
- * the multi-CU schedule (see medgp_nlml_grad_device) may block until their factorisation has finished. */
+ * (hipHostMalloc; pageable memory works but makes the copies synchronous).  A lane holds one call at a time. */
 void *medgp_host_alloc(size_t bytes);
 void  medgp_host_free(void *p);
 int   medgp_nlml_grad_async(medgp_ctx *ctx, int lane, int nbatch, const int32_t *slots, const double *theta, int flag_grad,

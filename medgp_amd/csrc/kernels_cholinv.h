@@ -853,15 +853,23 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 
 // grid = nbatch, block = NW * 64.  NW = 8: one workgroup per CU (lowest latency per patient);
 // NW = 4: two workgroups per CU, the serial diagonal-block phase of one overlaps the MFMA phase of the other.
-// only_small = 1: entries with more than one 64-block are left to the multi-CU schedule (kernels_cholinv_la.h); which
-// schedule factors an entry is a function of its own n and of how many LARGE entries the call holds, never of its batch-mates' sizes
+// sel = 0: every live entry.
+// sel = 1: only entries of a single 64-block; larger ones are left to the multi-CU schedule (kernels_cholinv_la.h) -- which
+//          schedule factors an entry is a function of its own n and of how many LARGE entries the call holds, never of its
+//          batch-mates' sizes.
+// sel = 2: only entries the multi-CU schedule has marked as failed (status -2: a pivot failed in its one attempt, or the test
+//          hook dbg_fail).  This is the device-driven continuation of the reference's retry loop (ref: c_inference_exact.cpp:
+//          99-111) for that schedule: the entry is re-assembled with one more noise addition and factored HERE, in-kernel loop
+//          and all, so a call that takes the multi-CU schedule needs no status read-back on the host.  Healthy entries cost
+//          one workgroup that loads a status word and leaves.
 template <int NW, int UPW>
-__global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int want_inv, int only_small) {
+__global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int want_inv, int sel) {
     constexpr int NT = NW * 64;
     __shared__ CholInvSmem<NW, UPW> sm;
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (L.status[b] < 0) return;
-    if (only_small && L.pn[L.bslot[b]] > 64) return;
+    const int st0 = L.status[b];
+    if (sel == 2 ? (st0 != -2) : (st0 < 0)) return;
+    if (sel == 1 && L.pn[L.bslot[b]] > 64) return;
 #ifdef CI_EXP_STAGGER
     // experiment: the second resident workgroup of a CU starts half a step late (anti-phase GEMM / serial phases)
     if (NW == 4 && ((CI_EXP_STAGGER_MODE == 0 && b >= (int)gridDim.x / 2) || (CI_EXP_STAGGER_MODE == 1 && (b & 1)))) {
@@ -874,6 +882,10 @@ __global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int wa
     const int n = __builtin_amdgcn_readfirstlane(L.pn[slot]);
     const int ld = L.ldn, npad = medgp_roundup(n, 64);
     int count = 0;
+    if (sel == 2) {   // attempt 0 was the multi-CU schedule's: continue with the first retry
+        count = 1;
+        reassemble_wg(L, b, slot, n, npad, count);
+    }
     while (true) {
         if (cholinv_attempt<NW, UPW>(L, b, slot, n, want_inv, sm) && count >= L.dbg_fail) break;
         __syncthreads();

@@ -330,72 +330,71 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
     } else
 #endif
     if (multi_cu) {
-        // The reference's retry loop (c_inference_exact.cpp:99-111: add the noise vector again, at most 10 times) is driven
-        // from the host here: a failed pivot leaves status -2; the failed problems restart with one more noise addition
-        // (L.jit), finished ones are recomputed identically (same inputs, same order of operations).
-        std::vector<int> hst(nbatch), hjit(nbatch, 0), nst(nbatch);
         // which entries the multi-CU schedule factors: more than one 64-block (host mirror of the patient sizes)
-        std::vector<uint8_t> big(nbatch, 1);
         bool any_small = false;
-        for (int bb = 0; bb < nbatch; bb++) {
-            big[bb] = entry_n[bb] > 64;
-            any_small = any_small || !big[bb];
-        }
-        LaArgs la{};
-        if (!c->mc_old) { int rc = ensure_la(c, nbatch, nt64, &la); if (rc) return rc; }
-        for (int attempt = 0;; attempt++) {
-            launch_assemble();
+        for (int bb = 0; bb < nbatch; bb++) any_small = any_small || entry_n[bb] <= 64;
 #ifdef MEDGP_LEGACY_AB
-            if (c->mc_old) {
+        if (c->mc_old) {
+            // first multi-CU schedule (two launches per step), host-driven retry loop: a failed pivot leaves status -2, the host
+            // bumps the jitter count of the failed problems and re-runs assembly + factorisation of the batch
+            std::vector<int> hst(nbatch), hjit(nbatch, 0), nst(nbatch);
+            for (int attempt = 0;; attempt++) {
+                launch_assemble();
                 for (int k = 0; k < nt64; k++) {
                     { Launcher l(c, KID_CI_PANEL, stream); hipLaunchKernelGGL(k_ci_panel, dim3(nbatch, nt64), dim3(MC_THREADS), 0, stream, L, k, want_mode); }
                     if (nt64 > 1) { Launcher l(c, KID_CI_TRSM, stream); hipLaunchKernelGGL(k_ci_trsm, dim3(nt64 - 1, nbatch), dim3(MC_THREADS), 0, stream, L, k, want_mode); }
                 }
                 hipLaunchKernelGGL(k_ci_finish, dim3(nbatch), dim3(256), 0, stream, L);
-            } else
-#endif
-            {
-                // entries of a single 64-block: one workgroup each (the same kernel, hence the same bits, as in any other call)
-                if (any_small) { Launcher l(c, KID_CHOLINV, stream); hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, want_mode, 1); }
-                // look-ahead schedule: one launch per 64-wide step (kernels_cholinv_la.h)
-                { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_prologue, dim3(nbatch, 1 + nt64), dim3(LA_THREADS), 0, stream, L, la, want_mode); }
-                for (int k = 0; k < nt64; k++) {
-                    const int nMF = std::max(nt64 - (k + 2), 0), nUF = (want_mode & 1) ? k + 1 : 0, nUL = (want_mode & 1) ? k : 0;
-                    const int nF = nMF + nUF + 1, nLrows = (k + 2 < nt64 && k >= 1) ? nMF + nUL + 1 : 0;
-                    const int nsl = std::min(la.maxslice, (k + LA_SLICE - 1) / LA_SLICE);   // history slices that exist at step k
-                    // single entry: park a sleeping workgroup where the dispatcher would put the chain's first neighbour (kernels_cholinv_la.h)
-                    const int ntask = 1 + nF + nLrows * nsl;
-                    // (workgroup ids are y * nbatch + x: with nbatch entries the chains are ids 0 .. nbatch-1 and their first neighbours
-                    //  ids 256 .. 256+nbatch-1, i.e. task y = 256 / nbatch of every entry)
-                    const int pk = (c->la_park > 0 && nbatch <= c->la_park_maxbatch && c->la_park % nbatch == 0) ? c->la_park / nbatch : -1;
-                    const int park = (pk > 0 && ntask > pk && k + 1 < nt64) ? pk : -1;
-                    Launcher l(c, KID_LA_STEP, stream);
-                    hipLaunchKernelGGL(k_la_step, dim3(nbatch, ntask + (park >= 0 ? 1 : 0)), dim3(LA_THREADS), 0, stream, L, la, k, want_mode, nLrows, park);
+                HIPCHK(c, hipMemcpyAsync(hst.data(), L.status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, stream));
+                HIPCHK(c, hipStreamSynchronize(stream));
+                if (attempt < c->dbg_fail) for (int bb = 0; bb < nbatch; bb++) if (hst[bb] >= 0) hst[bb] = -2;
+                bool retry = false, rewrite = false;
+                for (int bb = 0; bb < nbatch; bb++) {
+                    if (hst[bb] == -2) {
+                        if (hjit[bb] >= 10) { nst[bb] = -1; rewrite = true; }
+                        else { hjit[bb]++; nst[bb] = 0; retry = true; }
+                    } else nst[bb] = hst[bb];
                 }
-                { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_finish, dim3(nbatch, 4 * nt64), dim3(256), 0, stream, L, la, want_mode); }
+                if (!retry) {
+                    if (rewrite) HIPCHK(c, hipMemcpyAsync(L.status, nst.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, stream));
+                    if (rewrite) HIPCHK(c, hipStreamSynchronize(stream));
+                    break;
+                }
+                for (int bb = 0; bb < nbatch; bb++) if (nst[bb] > 0) nst[bb] = 0;
+                std::vector<double> zero4(4 * (size_t)nbatch, 0.0);
+                HIPCHK(c, hipMemcpyAsync(L.status, nst.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, stream));
+                HIPCHK(c, hipMemcpyAsync(L.jit, hjit.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, stream));
+                HIPCHK(c, hipMemcpyAsync(L.scal, zero4.data(), sizeof(double) * 4 * nbatch, hipMemcpyHostToDevice, stream));
+                HIPCHK(c, hipStreamSynchronize(stream));
             }
-            HIPCHK(c, hipMemcpyAsync(hst.data(), L.status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, stream));
-            HIPCHK(c, hipStreamSynchronize(stream));
-            if (attempt < c->dbg_fail)   // test hook: this attempt counts as failed for every live problem of this schedule
-                for (int bb = 0; bb < nbatch; bb++) if (hst[bb] >= 0 && (c->mc_old || big[bb])) hst[bb] = -2;
-            bool retry = false, rewrite = false;
-            for (int bb = 0; bb < nbatch; bb++) {
-                if (hst[bb] == -2) {
-                    if (hjit[bb] >= 10) { nst[bb] = -1; rewrite = true; }       // the reference's `return false`
-                    else { hjit[bb]++; nst[bb] = 0; retry = true; }
-                } else nst[bb] = hst[bb];                                       // -1 (n below the guard) or the jitter count
+        } else
+#endif
+        {
+            LaArgs la{};
+            { int rc = ensure_la(c, nbatch, nt64, &la); if (rc) return rc; }
+            launch_assemble();
+            // entries of a single 64-block: one workgroup each (the same kernel, hence the same bits, as in any other call)
+            if (any_small) { Launcher l(c, KID_CHOLINV, stream); hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, want_mode, 1); }
+            // look-ahead schedule: one launch per 64-wide step (kernels_cholinv_la.h)
+            { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_prologue, dim3(nbatch, 1 + nt64), dim3(LA_THREADS), 0, stream, L, la, want_mode); }
+            for (int k = 0; k < nt64; k++) {
+                const int nMF = std::max(nt64 - (k + 2), 0), nUF = (want_mode & 1) ? k + 1 : 0, nUL = (want_mode & 1) ? k : 0;
+                const int nF = nMF + nUF + 1, nLrows = (k + 2 < nt64 && k >= 1) ? nMF + nUL + 1 : 0;
+                const int nsl = std::min(la.maxslice, (k + LA_SLICE - 1) / LA_SLICE);   // history slices that exist at step k
+                // single entry: park a sleeping workgroup where the dispatcher would put the chain's first neighbour (kernels_cholinv_la.h)
+                const int ntask = 1 + nF + nLrows * nsl;
+                // (workgroup ids are y * nbatch + x: with nbatch entries the chains are ids 0 .. nbatch-1 and their first neighbours
+                //  ids 256 .. 256+nbatch-1, i.e. task y = 256 / nbatch of every entry)
+                const int pk = (c->la_park > 0 && nbatch <= c->la_park_maxbatch && c->la_park % nbatch == 0) ? c->la_park / nbatch : -1;
+                const int park = (pk > 0 && ntask > pk && k + 1 < nt64) ? pk : -1;
+                Launcher l(c, KID_LA_STEP, stream);
+                hipLaunchKernelGGL(k_la_step, dim3(nbatch, ntask + (park >= 0 ? 1 : 0)), dim3(LA_THREADS), 0, stream, L, la, k, want_mode, nLrows, park);
             }
-            if (!retry) {
-                if (rewrite) HIPCHK(c, hipMemcpyAsync(L.status, nst.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, stream));
-                if (rewrite) HIPCHK(c, hipStreamSynchronize(stream));
-                break;
-            }
-            for (int bb = 0; bb < nbatch; bb++) if (nst[bb] > 0) nst[bb] = 0;   // live again: k_ci_finish re-publishes the count
-            std::vector<double> zero4(4 * (size_t)nbatch, 0.0);                 // log-det accumulators restart
-            HIPCHK(c, hipMemcpyAsync(L.status, nst.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, stream));
-            HIPCHK(c, hipMemcpyAsync(L.jit, hjit.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, stream));
-            HIPCHK(c, hipMemcpyAsync(L.scal, zero4.data(), sizeof(double) * 4 * nbatch, hipMemcpyHostToDevice, stream));
-            HIPCHK(c, hipStreamSynchronize(stream));
+            { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_finish, dim3(nbatch, 4 * nt64), dim3(256), 0, stream, L, la, want_mode); }
+            // The reference's retry loop (c_inference_exact.cpp:99-111: add the noise vector again, at most 10 times), device
+            // driven: entries whose one attempt above failed (status -2) are re-assembled and factored by k_cholinv's in-kernel
+            // loop; for healthy entries this launch is one workgroup that reads a status word.  No host read-back, no wait.
+            { Launcher l(c, KID_CHOLINV, stream); hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, want_mode, 2); }
         }
     } else {
         launch_assemble();

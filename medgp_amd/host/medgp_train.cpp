@@ -161,7 +161,7 @@ int main(int argc, const char *argv[]) {
         else if (!strcmp(argv[i], "--thread") && i + 1 < argc) thread_num = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--max-batch") && i + 1 < argc) max_batch = atoi(argv[++i]);
-        else if (!strcmp(argv[i], "--host-threads") && i + 1 < argc) host_threads = atoi(argv[++i]);   // 0 = usable cores (<= 16)
+        else if (!strcmp(argv[i], "--host-threads") && i + 1 < argc) host_threads = atoi(argv[++i]);   // 0 = usable cores (<= 8)
         else if (!strcmp(argv[i], "--pingpong-min") && i + 1 < argc) pingpong_min = atoi(argv[++i]);   // active patients from which the lock-step loop splits them in two alternating halves
         else { cout << "Error: unknown argument: " << argv[i] << endl; return 1; }
     }
@@ -197,7 +197,7 @@ int main(int argc, const char *argv[]) {
     // (ref: dataio/c_experiment.cpp:254-309, D feature files each); a cohort is loaded by a pool of host threads over the
     // patients, the log lines are printed afterwards in patient order, and the whole cohort goes to the device as ONE packed
     // upload (medgp_set_patients: one transfer, one scatter kernel)
-    if (host_threads <= 0) host_threads = std::min(16, usable_cores());
+    if (host_threads <= 0) host_threads = std::min(8, usable_cores());
     WorkPool pool(std::max(1, host_threads));
     const auto t_load0 = std::chrono::steady_clock::now();
     vector<std::unique_ptr<Patient>> pts(pans.size());
@@ -352,19 +352,22 @@ int main(int argc, const char *argv[]) {
             groups.push_back(std::move(gp));
         }
     }
-    auto submit = [&](Group &g, int lane) -> bool {   // copy the requests of the group's active patients and queue the evaluation
-        vector<Patient *> act;
-        for (Patient *p : g.mem) if (p->active) act.push_back(p);
-        g.mem.swap(act);
+    // rows of g.th hold the pending requests of g.mem (same order); feed() refreshes them in the same parallel pass that runs the
+    // state machines, so a lock-step step costs ONE fork/join of the host threads
+    auto fill_requests = [&](Group &g) {
         g.nb = (int)g.mem.size();
-        if (g.nb == 0) return true;
-        g.slots.resize(g.nb);
         pool.parallel_for(g.nb, [&](int k) {
             Patient *p = g.mem[k];
-            g.slots[k] = p->slot;
             const vector<double> &rq = p->use_vem ? p->vem.request() : p->scg.request();
             std::copy(rq.begin(), rq.end(), g.th + (size_t)k * H);
         });
+    };
+    for (Group &g : groups) fill_requests(g);
+    auto submit = [&](Group &g, int lane) -> bool {   // queue the evaluation of the group's pending requests
+        g.nb = (int)g.mem.size();
+        if (g.nb == 0) return true;
+        g.slots.resize(g.nb);
+        for (int k = 0; k < g.nb; k++) g.slots[k] = g.mem[k]->slot;
         if (medgp_nlml_grad_async(ctx, lane, g.nb, g.slots.data(), g.th, 1, g.nl, g.gr, g.st)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
         total_evals += g.nb;
         return true;
@@ -383,10 +386,21 @@ int main(int argc, const char *argv[]) {
                 p->scg.feed(ok, g.nl[k], gk);
                 p->active = !p->scg.done();
             }
+            if (p->active) {   // next request into the same row (rows are compacted below when somebody finished)
+                const vector<double> &rq = p->use_vem ? p->vem.request() : p->scg.request();
+                std::copy(rq.begin(), rq.end(), g.th + (size_t)k * H);
+            }
         });
         vector<Patient *> ch;
-        for (int k = 0; k < g.nb; k++) if (dirty[k]) ch.push_back(g.mem[k]);
+        for (int k = 0; k < g.nb; k++) if (dirty[k] && g.mem[k]->active) ch.push_back(g.mem[k]);
         if (!upload_priors(ctx, ch, H, pool)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
+        int w = 0;
+        for (int k = 0; k < g.nb; k++) {
+            if (!g.mem[k]->active) continue;
+            if (w != k) { std::memmove(g.th + (size_t)w * H, g.th + (size_t)k * H, sizeof(double) * H); g.mem[w] = g.mem[k]; }
+            w++;
+        }
+        g.mem.resize(w);
         return true;
     };
     {

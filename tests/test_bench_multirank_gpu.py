@@ -15,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--steps", "2", "--warmup", "1", "--n", "128", "--no-extra", "--no-cpu-baseline"]
+COMMON = ["--steps", "2", "--warmup", "1", "--obs", "128", "--no-extra", "--no-cpu-baseline"]
 
 
 def _free_port():
