@@ -862,14 +862,17 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 //          99-111) for that schedule: the entry is re-assembled with one more noise addition and factored HERE, in-kernel loop
 //          and all, so a call that takes the multi-CU schedule needs no status read-back on the host.  Healthy entries cost
 //          one workgroup that loads a status word and leaves.
-template <int NW, int UPW>
-__global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int want_inv, int sel) {
+// (sel is a TEMPLATE parameter: as a run-time argument the extra entry paths moved hipcc's register allocation of the whole
+//  kernel -- one scratch reload inside the 64-MFMA chunk loop and three times the spill traffic in the panel solve of <4,4>)
+template <int NW, int UPW, int SEL>
+__global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int want_inv) {
     constexpr int NT = NW * 64;
+    constexpr int sel = SEL;
     __shared__ CholInvSmem<NW, UPW> sm;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int st0 = L.status[b];
-    if (sel == 2 ? (st0 != -2) : (st0 < 0)) return;
-    if (sel == 1 && L.pn[L.bslot[b]] > 64) return;
+    if constexpr (SEL == 2) { if (L.status[b] != -2) return; }
+    else { if (L.status[b] < 0) return; }
+    if constexpr (SEL == 1) { if (L.pn[L.bslot[b]] > 64) return; }
 #ifdef CI_EXP_STAGGER
     // experiment: the second resident workgroup of a CU starts half a step late (anti-phase GEMM / serial phases)
     if (NW == 4 && ((CI_EXP_STAGGER_MODE == 0 && b >= (int)gridDim.x / 2) || (CI_EXP_STAGGER_MODE == 1 && (b & 1)))) {
@@ -882,10 +885,11 @@ __global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int wa
     const int n = __builtin_amdgcn_readfirstlane(L.pn[slot]);
     const int ld = L.ldn, npad = medgp_roundup(n, 64);
     int count = 0;
-    if (sel == 2) {   // attempt 0 was the multi-CU schedule's: continue with the first retry
+    if constexpr (SEL == 2) {   // attempt 0 was the multi-CU schedule's: continue with the first retry
         count = 1;
         reassemble_wg(L, b, slot, n, npad, count);
     }
+    (void)sel;
     while (true) {
         if (cholinv_attempt<NW, UPW>(L, b, slot, n, want_inv, sm) && count >= L.dbg_fail) break;
         __syncthreads();

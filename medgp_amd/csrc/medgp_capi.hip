@@ -91,7 +91,7 @@ struct medgp_ctx {
     // profiling
     bool profiling = false;
     bool use_v0 = false;      // MEDGP_V0=1: baseline kernels (debug / A-B parity)
-    int cholinv_nw = 0;       // MEDGP_CHOLINV_NW=44|84 forces the workgroup shape (0 = auto)
+    int cholinv_nw = 0;       // MEDGP_CHOLINV_NW=44|84 forces the workgroup shape <waves, 16-row units per wave> (0 = auto)
     int la_park = 256;        // MEDGP_LA_PARK=<workgroup id>|0: where the look-ahead schedule parks its sleeping workgroup (0 = off)
     int la_park_maxbatch = 8; // MEDGP_LA_PARK_MAXBATCH: largest batch the parking is used for (measured: 4 x N=2048 -5 %, 16 x N=2048 +2 %)
     int force_mc = 0;         // MEDGP_MULTI_CU=1 forces / -1 forbids the multi-CU factorisation (0 = auto)
@@ -374,7 +374,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
             { int rc = ensure_la(c, nbatch, nt64, &la); if (rc) return rc; }
             launch_assemble();
             // entries of a single 64-block: one workgroup each (the same kernel, hence the same bits, as in any other call)
-            if (any_small) { Launcher l(c, KID_CHOLINV, stream); hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, want_mode, 1); }
+            if (any_small) { Launcher l(c, KID_CHOLINV, stream); hipLaunchKernelGGL((k_cholinv<8, 4, 1>), dim3(nbatch), dim3(512), 0, stream, L, want_mode); }
             // look-ahead schedule: one launch per 64-wide step (kernels_cholinv_la.h)
             { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_prologue, dim3(nbatch, 1 + nt64), dim3(LA_THREADS), 0, stream, L, la, want_mode); }
             for (int k = 0; k < nt64; k++) {
@@ -394,18 +394,22 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
             // The reference's retry loop (c_inference_exact.cpp:99-111: add the noise vector again, at most 10 times), device
             // driven: entries whose one attempt above failed (status -2) are re-assembled and factored by k_cholinv's in-kernel
             // loop; for healthy entries this launch is one workgroup that reads a status word.  No host read-back, no wait.
-            { Launcher l(c, KID_CHOLINV, stream); hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, want_mode, 2); }
+            { Launcher l(c, KID_CHOLINV, stream); hipLaunchKernelGGL((k_cholinv<8, 4, 2>), dim3(nbatch), dim3(512), 0, stream, L, want_mode); }
         }
     } else {
         launch_assemble();
         Launcher l(c, KID_CHOLINV, stream);
-        // more patients than CUs: 4-wave workgroups, two per CU (the serial diagonal phase of one overlaps the
-        // MFMA phase of the other); else 8 waves for the lowest latency per patient
-        const int shape = c->cholinv_nw ? c->cholinv_nw : (nbatch > c->num_cu ? 44 : 84);
-        if (shape == 44) hipLaunchKernelGGL((k_cholinv<4, 4>), dim3(nbatch), dim3(256), 0, stream, L, want_mode, 0);
-        else if (shape == 82) hipLaunchKernelGGL((k_cholinv<8, 2>), dim3(nbatch), dim3(512), 0, stream, L, want_mode, 0);
-        else if (shape == 42) hipLaunchKernelGGL((k_cholinv<4, 2>), dim3(nbatch), dim3(256), 0, stream, L, want_mode, 0);
-        else hipLaunchKernelGGL((k_cholinv<8, 4>), dim3(nbatch), dim3(512), 0, stream, L, want_mode, 0);
+        // more patients than CUs: 4-wave workgroups, two per CU (the serial diagonal phase of one overlaps the MFMA phase of the
+        // other).  At most one patient per CU: 8 waves (8 block slots per pass) once a step has more than 4 row blocks, else the
+        // 4-wave shape, whose 4 slots already cover every block of n <= 256 (measured, 256 patients x N=256, D=2: <4,4> 0.211 ms,
+        // <8,4> 0.232 ms -- half of its 8 slots idle).
+        // Only shapes with at most two waves per SIMD are instantiated: the out-of-line diagonal factor (diag_factor_wave) is
+        // compiled ONCE for the tightest register budget among its callers -- with a <*,2> shape (four waves per SIMD, 128 VGPRs)
+        // in the library it is held to 128 VGPRs and carries 182 scratch accesses on the serial path of EVERY shape (248 VGPRs and
+        // 18 without; found when the legacy k_ci_panel caller that had masked this left the build: k_cholinv<4,4> 1.37 -> 1.48 ms).
+        const int shape = c->cholinv_nw ? c->cholinv_nw : ((nbatch > c->num_cu || nt64 <= 4) ? 44 : 84);
+        if (shape == 44) hipLaunchKernelGGL((k_cholinv<4, 4, 0>), dim3(nbatch), dim3(256), 0, stream, L, want_mode);
+        else hipLaunchKernelGGL((k_cholinv<8, 4, 0>), dim3(nbatch), dim3(512), 0, stream, L, want_mode);
     }
     int from_slab = 0;
 #ifdef MEDGP_STAMPS
