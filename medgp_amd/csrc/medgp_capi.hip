@@ -267,7 +267,7 @@ int ensure_la(medgp_ctx *c, int nbatch, int nbmax, LaArgs *out) {
     A.maxslice = (nbmax + LA_SLICE - 1) / LA_SLICE;
     A.rows = 2 * nbmax + 1;
     const size_t need_part = (size_t)nbatch * 2 * A.rows * A.maxslice * 4096;
-    const size_t need_small = (size_t)nbatch * (64 * (size_t)c->ldn + 4 * 4096 + 1);
+    const size_t need_small = (size_t)nbatch * (64 * (size_t)c->ldn + 6 * 4096 + 1);
     auto grow = [&](double **p, size_t *cap, size_t need) -> int {
         if (need <= *cap) return MEDGP_OK;
         HIPCHK(c, hipDeviceSynchronize());   // the old scratch may still be read by kernels queued on any of the context's streams
@@ -288,7 +288,8 @@ int ensure_la(medgp_ctx *c, int nbatch, int nbmax, LaArgs *out) {
     A.ybuf = c->d_la_small;
     A.xk2 = c->d_la_small + (size_t)nbatch * 64 * c->ldn;
     A.pnx = A.xk2 + (size_t)nbatch * 2 * 4096;
-    A.flag = (int *)(A.pnx + (size_t)nbatch * 2 * 4096);
+    A.dterm = A.pnx + (size_t)nbatch * 2 * 4096;
+    A.flag = (int *)(A.dterm + (size_t)nbatch * 2 * 4096);
     *out = A;
     return MEDGP_OK;
 }
