@@ -37,9 +37,13 @@ struct LaArgs {
     double *pnx;          // [batch][2][64*64]  copy of the pre-solve block P_k+1,k (row-major), indexed by panel parity: every
                           //                    workgroup of step k re-derives L[C_k+1,C_k] from it while D overwrites the
                           //                    in-place block with the solved values
-    double *dterm;        // [batch][2][64*64]  head start of the NEXT-but-one diagonal block, indexed by block parity: -K[blk, blk] + the
-                          //                    rank-64 term of the panel finished in this launch, written by the F workgroup of that row
-                          //                    block (see k_la_step, "diagonal head start"); same element layout as a partial-sum slab
+    double *dterm;        // [batch][2][64*64]  head start of the NEXT launch's diagonal block, indexed by block parity: -K[blk, blk] + every
+                          //                    history term up to the panel finished in this launch, written by the F workgroup of that
+                          //                    row block (see k_la_step, "diagonal head start"); element layout of a partial-sum slab
+    double *dsum;         // [batch][2][64*64]  sum of the diagonal look-ahead slices of a block (written by the R workgroup one launch
+                          //                    before the chain reads it), indexed by block parity
+    double *dpart;        // [batch][2][maxslice][64*64]  look-ahead partial sums of a DIAGONAL block (block x block^T over history
+                          //                    slices), written two launches before the chain needs the block, indexed by block parity
     int *flag;            // [batch] step counter of the diagonal chain: k + 1 once the D workgroup of step k is done (parking, below)
     int nbmax;            // 64-blocks of the largest patient of the batch
     int maxslice;         // slices per row block the scratch is dimensioned for
@@ -200,7 +204,7 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
 }
 
 // ---- one step ----------------------------------------------------------------------------------------------------------
-// grid = (nbatch, ntask): task 0 = D, tasks 1 .. nF = F (row blocks), then L tasks (slice-major: slice x row block, nLrowsL
+// grid = (nbatch, ntask): task 0 = D, tasks 1 .. nF = F (row blocks), task nF + 1 = R, then L tasks (slice-major: slice x row block, nLrowsL
 // row-block slots per slice as counted by the host for the largest entry).
 // Row-block enumeration for F at step k (panel k is finished, panel k+1 prepared):
 //   M_i, i = k+2 .. nb-1   |  U_rho, rho = 0 .. k (inverse only)  |  Y
@@ -263,6 +267,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     const int nF = nM_F + nU_F + 1;
     LaRow row;
     int role, slice = 0;
+    bool diag_ahead = false;
     if (task == 0) { role = 0; row.kind = 0; row.blk = k + 1; }
     else if (task <= nF) {
         role = 1;
@@ -270,6 +275,8 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
         if (t < nM_F) { row.kind = 0; row.blk = k + 2 + t; }
         else if (t < nM_F + nU_F) { row.kind = 1; row.blk = t - nM_F; }
         else { row.kind = 2; row.blk = 0; }
+    } else if (task == nF + 1) {
+        role = 3; row.kind = 0; row.blk = k + 2;   // R: sum of the diagonal look-ahead slices of block k+2
     } else {
         role = 2;
         // slice-major, and only the ceil(k / LA_SLICE) slices that exist at this step are launched: the L tasks that have work
@@ -277,18 +284,56 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
         // maxslice slots per row put the live tasks -- slices 0, 1 of every row early on -- at ids = 0, 1 mod 16, i.e. on TWO
         // of the eight XCDs, behind ~850 empty workgroups: at N = 4096 the L role ended at 49 us of a step whose diagonal
         // chain needs 34 us.)
-        int t = task - 1 - nF;
+        int t = task - 2 - nF;
         slice = t / nLrowsL;
         t -= slice * nLrowsL;
         if (slice >= A.maxslice) return;
         const int nU_L = want_inv ? k : 0;
-        if (t < nM_F) { row.kind = 0; row.blk = k + 2 + t; }
+        // slot 0 of every slice used to be row M_k+2 of panel k+2 -- the NEXT diagonal block, consumed by the chain alone.  The chain
+        // now gets its block ready-made (diagonal head start), so the slot instead looks one block further ahead: partial sums of
+        // the diagonal block k+3 (rows of block k+3 times themselves) over the same history slice, summed by the F workgroup of that
+        // row block in the next launch -- off the chain.
+        diag_ahead = (t == 0 && nM_F >= 1);
+        if (diag_ahead) { row.kind = 0; row.blk = k + 3; }
+        else if (t < nM_F) { row.kind = 0; row.blk = k + 2 + t; }
         else if (t < nM_F + nU_L) { row.kind = 1; row.blk = t - nM_F; }
         else if (t == nM_F + nU_L) { row.kind = 2; row.blk = 0; }
         else return;
     }
     if (row.kind == 0 && row.blk >= nb && !(role == 0)) return;   // beyond this patient's blocks
     double *Rb = la_row_base(L, A, b, row);
+
+    // ============================== R: diagonal look-ahead slices of block k+2 -> one slab ===============================
+    // (slices over panels 0 .. k-2, written by the diag-ahead L tasks of the previous launch; read by the chain of the next launch
+    //  together with A.dterm.  All loads of a group of four slices are independent; fixed summation order.)
+    if (role == 3) {
+        if (k + 2 >= nb) return;
+        const int nsd = (k >= 2) ? (k - 1 + LA_SLICE - 1) / LA_SLICE : 0;
+        const double *Dp = A.dpart + (((size_t)b * 2 + ((k + 2) & 1)) * A.maxslice) * 4096 + (size_t)w * 1024 + lane;
+        double sacc[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) sacc[e] = 0.0;
+        int sd = 0;
+        for (; sd + 3 < nsd; sd += 4) {
+            double pv[4][16];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) pv[u][e] = Dp[(size_t)(sd + u) * 4096 + e * 64];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) sacc[e] += pv[u][e];
+        }
+        for (; sd < nsd; sd++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) sacc[e] += Dp[(size_t)sd * 4096 + e * 64];
+        }
+        double *Ds = A.dsum + ((size_t)b * 2 + ((k + 2) & 1)) * 4096 + (size_t)w * 1024 + lane;
+#pragma unroll
+        for (int e = 0; e < 16; e++) Ds[e * 64] = sacc[e];
+        return;
+    }
 
     // ============================== L: look-ahead partial sum of panel k+2 =============================================
     if (role == 2) {
@@ -300,8 +345,10 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
         v4d acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ct++) acc[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
-        la_gemm(Rb, Lb + (size_t)(64 * (k + 2)) * ld, ld, j0, j1, acc, sm, tid, w, li, g);
-        double *P = la_part(A, b, (k + 2) & 1, row, slice) + (size_t)w * 1024 + lane;
+        // shared operand: the rows of block k+2 (panel k+2), or -- diagonal look-ahead -- the task's own rows (block k+3)
+        la_gemm(Rb, Lb + (size_t)(64 * (diag_ahead ? k + 3 : k + 2)) * ld, ld, j0, j1, acc, sm, tid, w, li, g);
+        double *P = (diag_ahead ? A.dpart + (((size_t)b * 2 + ((k + 3) & 1)) * A.maxslice + slice) * 4096
+                                : la_part(A, b, (k + 2) & 1, row, slice)) + (size_t)w * 1024 + lane;
 #pragma unroll
         for (int ct = 0; ct < 4; ct++)
 #pragma unroll
@@ -336,23 +383,31 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
 #pragma unroll
     for (int ct = 0; ct < 4; ct++) acc[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
     const int jf = la_first_panel(row);
-    // Diagonal head start (D role, k >= 1): the F workgroup of row block k+1 left  -K[k+1, k+1] + row[C_k-1] row[C_k-1]^T  in
-    // A.dterm during the previous launch (it held those rows of panel k-1 in registers anyway), so the chain neither loads its
-    // initial block nor runs the 64 x 64 x 64 product of panel k-1: about 8 k cycles (3 us) less on the critical path of every step.
+    // Diagonal head start (D role, k >= 1): the F workgroup of row block k+1 left  -K[k+1, k+1] + sum_{j <= k-1} row[C_j] row[C_j]^T
+    // in A.dterm during the previous launch (panel k-1 from its registers, panel k-2 as a 64 x 64 x 64 product, everything older
+    // from the diagonal look-ahead slices A.dpart), so the chain neither loads its initial block, nor walks the chain of partial-sum
+    // round trips (0.9 us per two slices, up to 15 slices at N = 4096), nor runs the product of panel k-1.
     const bool head_start = is_D && k >= 1;
     if (has_next) {
         if (head_start) {
             const double *Dt = A.dterm + ((size_t)b * 2 + ((k + 1) & 1)) * 4096 + (size_t)w * 1024 + lane;
+            const double *Ds = A.dsum + ((size_t)b * 2 + ((k + 1) & 1)) * 4096 + (size_t)w * 1024 + lane;
+            double dtv[16], dsv[16];
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] = Dt[e * 64];
+            for (int e = 0; e < 16; e++) dtv[e] = Dt[e * 64];
+#pragma unroll
+            for (int e = 0; e < 16; e++) dsv[e] = Ds[e * 64];     // (written by the R workgroup of the previous launch, k >= 1: zeros when there were no slices)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] = dtv[e] + dsv[e];
         } else if (row.kind != 1) {   // K rows and the y row carry their own initial values in place; U rows start from zero
 #pragma unroll
             for (int ct = 0; ct < 4; ct++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) acc[ct][r] = -Rb[(size_t)(16 * w + 4 * r + g) * ld + c1 + 16 * ct + li];
         }
-        // partial sums over history panels jf .. k-2, written by the L tasks of the previous launch
-        const int hist_end = k - 1;               // panels jf .. hist_end-1
+        // partial sums over history panels jf .. k-2, written by the L tasks of the previous launch (the chain's block arrives
+        // with them already added)
+        const int hist_end = head_start ? jf : k - 1;               // panels jf .. hist_end-1
         // (two slices per iteration, both requested before either is added: the loop is a chain of memory round trips --
         //  0.9 us per slice on the diagonal chain, 15 slices at the end of N = 4096; the order of the additions is unchanged)
         const int nsum = (hist_end - jf + LA_SLICE - 1) / LA_SLICE;
@@ -448,6 +503,11 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
                     for (int cb = 0; cb < 4; cb++)
                         acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sm.Xs[16 * cb + li][16 * ct + 4 * r + g], acc[cb], 0, 0, 0);
                 }
+            // ... + panel k-1 (final since the previous launch); the diagonal look-ahead slices over panels 0 .. k-2 are summed by
+            // the R workgroup of this launch into A.dsum (left to this workgroup, its chain of up to 15 slab round trips made it
+            // the longest task of the launch at N = 4096)
+            __syncthreads();   // the rows in Xs have been read: la_gemm stages through the same LDS
+            if (k >= 1) la_gemm(Rb, Lb + (size_t)c2 * ld, ld, k - 1, k, acc, sm, tid, w, li, g);
             double *Dt = A.dterm + ((size_t)b * 2 + ((k + 2) & 1)) * 4096 + (size_t)w * 1024 + lane;
 #pragma unroll
             for (int e = 0; e < 16; e++) Dt[e * 64] = acc[e >> 2][e & 3];
