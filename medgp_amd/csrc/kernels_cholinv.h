@@ -724,38 +724,50 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 //  loops and 376 scratch operations into the factor: 2.30 ms at 512 patients against 1.38 ms for <4,4>)
                 if (wave == 0) diag_factor_wave((ld_t *)&sm.Dk[0][0], (ld_t *)&sm.Xk[0][0], (ld_t *)sm.rhs, (li_t *)&sm.fail, (ld_t *)&sm.logdet, lane);
 #endif
+                __syncthreads();   // factor done: Dk = L_kk, Xk = L_kk^-1 (or fail)
+                STAMP(3);   // diagonal factor
+                if (sm.fail) return false;
                 if (wave == 0) {
-                    STAMP(3);   // diagonal factor
-                    if (!sm.fail) {
-                        // z_k = L_kk^-1 (y_k - zacc).  Xk has exact zeros above the diagonal, so the fixed-length loops
-                        // below add the same terms in the same order as triangular loops, but pipeline their LDS reads
-                        sm.rhs[lane] = ((c0 + lane < n) ? y[c0 + lane] : 0.0) - zacc;
+                    // z_k = L_kk^-1 (y_k - zacc).  Xk has exact zeros above the diagonal, so fixed-length loops add the same terms
+                    // as triangular ones, and the 64 terms are split over four independent accumulators (columns c, c+16, c+32,
+                    // c+48): the dependent FMA chain is 16 long instead of 64 -- next to a co-resident MFMA stream every link of
+                    // that chain waits for the pipe (11 k cycles per panel in situ for the two solves with one accumulator each)
+                    sm.rhs[lane] = ((c0 + lane < n) ? y[c0 + lane] : 0.0) - zacc;
+                    __builtin_amdgcn_wave_barrier();
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                    for (int cc = 0; cc < 16; cc++) {
+                        s0 += sm.Xk[lane][cc] * sm.rhs[cc];
+                        s1 += sm.Xk[lane][cc + 16] * sm.rhs[cc + 16];
+                        s2 += sm.Xk[lane][cc + 32] * sm.rhs[cc + 32];
+                        s3 += sm.Xk[lane][cc + 48] * sm.rhs[cc + 48];
+                    }
+                    const double s = (s0 + s1) + (s2 + s3);
+                    zz[c0 + lane] = s;
+                    sm.zk[lane] = s;
+                    if (c0 + lane < 1024) sm.zs[c0 + lane] = s;
+                    if (want_inv) {
+                        // alpha = U z accumulated panel by panel; the diagonal block U_kk = L_kk^-T opens rows C_k
                         __builtin_amdgcn_wave_barrier();
-                        double s = 0.0;
-#pragma unroll 16
-                        for (int cc = 0; cc < 64; cc++) s += sm.Xk[lane][cc] * sm.rhs[cc];
-                        zz[c0 + lane] = s;
-                        sm.zk[lane] = s;
-                        if (c0 + lane < 1024) sm.zs[c0 + lane] = s;
-                        if (want_inv) {
-                            // alpha = U z accumulated panel by panel; the diagonal block U_kk = L_kk^-T opens rows C_k
-                            __builtin_amdgcn_wave_barrier();
-                            double a0 = 0.0;
-#pragma unroll 16
-                            for (int cc = 0; cc < 64; cc++) a0 += sm.Xk[cc][lane] * sm.zk[cc];
-                            alpha[c0 + lane] = a0;
+                        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                        for (int cc = 0; cc < 16; cc++) {
+                            a0 += sm.Xk[cc][lane] * sm.zk[cc];
+                            a1 += sm.Xk[cc + 16][lane] * sm.zk[cc + 16];
+                            a2 += sm.Xk[cc + 32][lane] * sm.zk[cc + 32];
+                            a3 += sm.Xk[cc + 48][lane] * sm.zk[cc + 48];
                         }
+                        alpha[c0 + lane] = (a0 + a1) + (a2 + a3);
+                    }
+                } else {
+                    // meanwhile the other waves store L_kk (lower) and U_kk = L_kk^-T (upper, zeros below)
+                    for (int e = (wave - 1) * 64 + lane; e < 64 * 64; e += NT - 64) {   // waves 1 .. NW-1
+                        int rr = e >> 6, cc = e & 63;
+                        if (cc <= rr) Lb[(size_t)(c0 + rr) * ld + c0 + cc] = sm.Dk[rr][cc];
+                        if (store_ukk) Ub[(size_t)(c0 + rr) * ld + c0 + cc] = (cc >= rr) ? sm.Xk[cc][rr] : 0.0;
                     }
                 }
-                __syncthreads();
-                STAMP(2);   // z / alpha solves of wave 0, or waiting for the diagonal phase
-                if (sm.fail) return false;
-                // store L_kk (lower) and U_kk = L_kk^-T (upper, zeros below)
-                for (int e = tid; e < 64 * 64; e += NT) {
-                    int rr = e >> 6, cc = e & 63;
-                    if (cc <= rr) Lb[(size_t)(c0 + rr) * ld + c0 + cc] = sm.Dk[rr][cc];
-                    if (store_ukk) Ub[(size_t)(c0 + rr) * ld + c0 + cc] = (cc >= rr) ? sm.Xk[cc][rr] : 0.0;
-                }
+                STAMP(2);   // z / alpha solves of wave 0 beside the L_kk / U_kk stores of the others
                 // Dk fully read before the store slabs (same LDS) are written: LDS-only barrier (no wait for the global
                 // stores above, which nobody reads before the next step)
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
