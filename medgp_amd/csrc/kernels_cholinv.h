@@ -59,6 +59,21 @@ __device__ __forceinline__ v2d ci_bload(__amdgpu_buffer_rsrc_t rs, int voff, int
 #ifndef CI_SLAB_INIT
 #define CI_SLAB_INIT 1
 #endif
+// A/B switches (default off): wave priority of the VALU / LDS phases around the MFMA loop (-DCI_EXP_PRIO_INIT=n, -DCI_EXP_PRIO_TRSM=n)
+#ifdef CI_EXP_PRIO_INIT
+#define CI_PRIO_INIT_ON() __builtin_amdgcn_s_setprio(CI_EXP_PRIO_INIT)
+#define CI_PRIO_INIT_OFF() __builtin_amdgcn_s_setprio(0)
+#else
+#define CI_PRIO_INIT_ON() do {} while (0)
+#define CI_PRIO_INIT_OFF() do {} while (0)
+#endif
+#ifdef CI_EXP_PRIO_TRSM
+#define CI_PRIO_TRSM_ON() __builtin_amdgcn_s_setprio(CI_EXP_PRIO_TRSM)
+#define CI_PRIO_TRSM_OFF() __builtin_amdgcn_s_setprio(0)
+#else
+#define CI_PRIO_TRSM_ON() do {} while (0)
+#define CI_PRIO_TRSM_OFF() do {} while (0)
+#endif
 #ifndef CI_SLAB_STORE
 #define CI_SLAB_STORE 1
 #endif
@@ -91,6 +106,11 @@ struct CholInvSmem {
 static_assert(sizeof(CholInvSmem<4, 4>) <= 80 * 1024, "two 4-wave workgroups per CU need <= 80 KB each");
 
 #define CI_S 66   // LDS row stride (doubles) of Dk / Xk
+// v_mfma_f64_16x16x4_f64 takes its last immediate (BLGP) as NEG[a, b, c]: 1 = the product enters with the opposite sign, for free
+// (-(a b) + c is the same correctly rounded FMA as (-a) b + c: results are bit-identical to an explicit v_xor of the operand).
+// Every "-x" that used to feed an MFMA (48 v_xor per pass in the panel solve, 64 in the panel init, the trailing updates of the
+// diagonal factor) is gone: next to the co-resident workgroup's MFMA stream each VALU instruction waits for the pipe.
+#define MFMA_NEGA 1
 
 __device__ inline double readlane_d(double v, int srclane) {   // srclane must be wave-uniform
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -283,7 +303,7 @@ __device__ __forceinline__ void diag_factor_wave_body(ld_t *D, ld_t *X, ld_t *dv
             for (int si = 0; si < 3; si++)
 #pragma unroll
                 for (int ui = 0; ui <= si; ui++)
-                    if (t + 1 + si < 4) dc[si][ui] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lt[si][r], lt[ui][r], dc[si][ui], 0, 0, 0);
+                    if (t + 1 + si < 4) dc[si][ui] = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[si][r], lt[ui][r], dc[si][ui], 0, 0, MFMA_NEGA);
 #pragma unroll
         for (int si = 0; si < 3; si++)
 #pragma unroll
@@ -312,14 +332,14 @@ __device__ __forceinline__ void diag_factor_wave_body(ld_t *D, ld_t *X, ld_t *dv
         }
         double xs[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) xs[r] = -TX(s2, s2)[li * CI_S + 4 * r + g];
+        for (int r = 0; r < 4; r++) xs[r] = TX(s2, s2)[li * CI_S + 4 * r + g];
         v4d xo[3];
 #pragma unroll
         for (int t = 0; t < s2; t++) xo[t] = zero4;
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int t = 0; t < s2; t++) xo[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[r], pp[t][r], xo[t], 0, 0, 0);
+            for (int t = 0; t < s2; t++) xo[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[r], pp[t][r], xo[t], 0, 0, MFMA_NEGA);
 #pragma unroll
         for (int t = 0; t < s2; t++) tile_st(TX(s2, t), xo[t], li, g);
         __builtin_amdgcn_wave_barrier();
@@ -366,14 +386,14 @@ __device__ __forceinline__ void inv_row_tiles(ld_t *D, ld_t *X, int s2, int t, i
     for (int u = t; u < s2; u++) pp = tile_mm<false, false>(TD(s2, u), TX(u, t), pp, li, g);
     v4d xo = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int r = 0; r < 4; r++) xo = __builtin_amdgcn_mfma_f64_16x16x4f64(-TX(s2, s2)[li * CI_S + 4 * r + g], pp[r], xo, 0, 0, 0);
+    for (int r = 0; r < 4; r++) xo = __builtin_amdgcn_mfma_f64_16x16x4f64(TX(s2, s2)[li * CI_S + 4 * r + g], pp[r], xo, 0, 0, MFMA_NEGA);
     tile_st(TX(s2, t), xo, li, g);
 }
 __device__ __forceinline__ void trail_tile(ld_t *D, int s2, int u, int t, int li, int g) {
     v4d c = tile_ld(TD(s2, u), li, g);
 #pragma unroll
     for (int k = 0; k < 4; k++)
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-TD(s2, t)[li * CI_S + 4 * k + g], TD(u, t)[li * CI_S + 4 * k + g], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(TD(s2, t)[li * CI_S + 4 * k + g], TD(u, t)[li * CI_S + 4 * k + g], c, 0, 0, MFMA_NEGA);
     tile_st(TD(s2, u), c, li, g);
 }
 // (inlined into its callers: as an out-of-line function it claimed 248 VGPRs + 32 AGPRs for callee-saved traffic, and a kernel is
@@ -484,7 +504,7 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
                 if (hct < 7) a_nxt = *(const v2d *)&sm.Bs[buf][16 * ((hct + 1) & 3) + li][8 * ((hct + 1) >> 2) + 2 * g]; \
                 _Pragma("unroll") for (int s = 0; s < 2; s++)                                                      \
                     _Pragma("unroll") for (int u = 0; u < NA; u++)                                                 \
-                        acc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[s], hc[u][h][s], acc[ct][u], 0, 0, 0); \
+                        acc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[s], hc[u][h][s], acc[ct][u], 0, 0, MFMA_NEGA); \
                 a_cur = a_nxt;                                                                                     \
                 if (ct == 3) {   /* half h is consumed: request it for the next chunk */                           \
                     _Pragma("unroll") for (int u = 0; u < NA; u++) { CI_HLOAD(u, h, cn); }                         \
@@ -595,8 +615,8 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
             // first chunk anybody in the workgroup needs: slot 0 of group 0 has the longest history
             const int bidx0 = pass * BPP;
             const int cstart = (bidx0 < nM) ? 0 : (64 * (bidx0 - nM)) / CI_KC;
-            // acc starts at -init (init = K block for K rows, 0 for U rows); the history GEMM adds P, so the panel
-            // value is  init - P = -acc  (the sign is folded into the operands that consume acc)
+            // acc starts at init (init = K block for K rows, 0 for U rows); the history GEMM subtracts P (MFMA negation modifier),
+            // so acc is the panel value  init - P  itself
             // Panel init through the same per-wave slab as the panel stores: row-contiguous 16-byte loads (8 whole lines per
             // instruction), transposition in LDS.  The loads must be UNCONDITIONAL inside the block (units without a K
             // block read slot 0's and discard it): with a branch per unit hipcc spilled four accumulator tiles inside the
@@ -604,6 +624,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
             // transposed layout (1.69 -> 1.64 ms at 512 x N=512).
 #if CI_SLAB_INIT
             v4d acc[4][UPW];
+            CI_PRIO_INIT_ON();
             {
                 CI_SLAB_LANE();
                 bool ldu[UPW], anyld = false;
@@ -613,6 +634,9 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     // all 64 columns are requested at once (the registers the accumulators will occupy are free here): one
                     // memory round trip per pass instead of one per 32-column half
                     v2d kin[4][2 * UPW];
+                    double fsel[UPW];
+#pragma unroll
+                    for (int u = 0; u < UPW; u++) fsel[u] = ldu[u] ? 1.0 : 0.0;
 #pragma unroll
                     for (int u = 0; u < UPW; u++) {
                         const gd_t *src = (ldu[u] ? ub[u] : ub[0]) + (size_t)srow8 * ld + c0 + 2 * spc;
@@ -633,7 +657,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
                                 const double kv = S[16 * u + (lane_o & 15)][4 * r + (lane_o >> 4)];
-                                acc[ct][u][r] = ldu[u] ? -kv : 0.0;
+                                acc[ct][u][r] = kv * fsel[u];   // one multiply by 1 / 0 (two v_cndmask per double as a select)
                             }
                         __builtin_amdgcn_wave_barrier();
                     }
@@ -653,10 +677,11 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
                     if (act[u] && isM[u]) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++) acc[ct][u][r] = -ub[u][(size_t)li * ld + c0 + 16 * ct + 4 * r + g];
+                        for (int r = 0; r < 4; r++) acc[ct][u][r] = ub[u][(size_t)li * ld + c0 + 16 * ct + 4 * r + g];
                     }
                 }
 #endif
+            CI_PRIO_INIT_OFF();
             STAMP(0);   // panel init
             double zsum = 0.0;
             // ---- GEMM over the history, B chunk (L[C_k rows]) staged through LDS, double buffered
@@ -703,7 +728,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                     for (int ct = 0; ct < 4; ct++)
 #pragma unroll
-                        for (int r = 0; r < 4; r++) sm.Dk[16 * wu + li][16 * ct + 4 * r + g] = -acc[ct][0][r];
+                        for (int r = 0; r < 4; r++) sm.Dk[16 * wu + li][16 * ct + 4 * r + g] = acc[ct][0][r];
                 }
                 sm.zpart[wave][lane] = zsum;
                 __syncthreads();
@@ -773,7 +798,8 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             STAMP(3);   // L_kk / U_kk stores (folded into diag)
-            // ---- triangular solve as GEMM: out^T[ct] = sum_{ct' <= ct} (-Xk[ct, ct']) acc^T[ct'] on all four units (an
+            CI_PRIO_TRSM_ON();
+            // ---- triangular solve as GEMM: out^T[ct] = sum_{ct' <= ct} Xk[ct, ct'] acc^T[ct'] on all four units (an
             //      inactive or diagonal unit computes on zeros / unused values: 40 MFMAs, never stored); each 16-column
             //      slab goes through the wave's LDS slab and leaves as whole 128-byte lines
             {
@@ -793,7 +819,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     for (int cp = 0; cp <= ct; cp++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            double a = -sm.Xk[16 * ct + li][16 * cp + 4 * r + g];
+                            double a = sm.Xk[16 * ct + li][16 * cp + 4 * r + g];
 #pragma unroll
                             for (int u = 0; u < UPW; u++) o[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[cp][u][r], o[u], 0, 0, 0);
                         }
@@ -845,6 +871,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     }
                 }
             }
+            CI_PRIO_TRSM_OFF();
             STAMP(5);   // panel solve + stores
             // Visibility of this pass's stores: columns C_k are first read in step k + 1, at chunk 4k - 1 (B staging) or
             // later, i.e. after >= 3 chunk barriers (each a full __syncthreads with vmcnt(0)) when k >= 1 -- no need to
