@@ -491,11 +491,24 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
         _Pragma("unroll") for (int u = NA0; u < UPW; u++)                                                          \
             if (u < (NA1)) { CI_HLOAD(u, 0, (cc)); CI_HLOAD(u, 1, (cc)); }                                         \
     }
+// Staging of the shared operand: chunk c + 1 is stored into LDS at the end of iteration c.  CI_STAGE_DEEP=1 requests it TWO
+// iterations ahead (a second register set of SPT doubles) instead of at the top of the iteration that stores it.
+#ifndef CI_STAGE_DEEP
+#define CI_STAGE_DEEP 0
+#endif
+#if CI_STAGE_DEEP
+#define CI_STAGE_LOAD(c, cn) { const int cn2 = ((c) + 2 < nch) ? (c) + 2 : nch - 1;                                 \
+        _Pragma("unroll") for (int e = 0; e < SPT; e++) bnn[e] = Bsrc[cn2 * CI_KC + e]; }
+#define CI_STAGE_ROTATE() { _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = bnn[e]; }
+#else
+#define CI_STAGE_LOAD(c, cn) { _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[(cn) * CI_KC + e]; }
+#define CI_STAGE_ROTATE() {}
+#endif
 #define CI_CHUNK_PHASE(NA, lo, hi)                                                                                 \
     for (int c = (lo); c < (hi); c++) {                                                                            \
         const int buf = c & 1;                                                                                     \
         const int cn = (c + 1 < nch) ? c + 1 : c;                 /* next chunk, clamped */                        \
-        _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[cn * CI_KC + e];                           \
+        CI_STAGE_LOAD(c, cn)                                                                                      \
         if (NA > 0) {                                                                                              \
             v2d a_cur = *(const v2d *)&sm.Bs[buf][li][2 * g];                                                      \
             _Pragma("unroll") for (int hct = 0; hct < 8; hct++) {                                                  \
@@ -526,6 +539,7 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
         if (c + 1 < nch) {                                                                                         \
             _Pragma("unroll") for (int e = 0; e < SPT; e++) sm.Bs[buf ^ 1][srow][scol + e] = bnext[e];             \
         }                                                                                                          \
+        CI_STAGE_ROTATE()                                                                                          \
         STAMP(6); /* staging store (waits for this iteration's B loads) */                                         \
         __syncthreads();                                                                                           \
         STAMP(7); /* chunk barrier wait */                                                                         \
@@ -691,11 +705,21 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 const int srow = (tid * SPT) / CI_KC, scol = (tid * SPT) % CI_KC;
                 const gd_t *Bsrc = Lb + (size_t)(c0 + srow) * ld + scol;
                 double bnext[SPT];
+#if CI_STAGE_DEEP
+                double bnn[SPT];
+#endif
 #pragma unroll
                 for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[cstart * CI_KC + e];
                 __syncthreads();   // every wave is done with its init slab (St aliases Bs)
 #pragma unroll
                 for (int e = 0; e < SPT; e++) sm.Bs[cstart & 1][srow][scol + e] = bnext[e];
+#if CI_STAGE_DEEP
+                {   // chunk cstart + 1 is on its way before the loop starts
+                    const int c1 = (cstart + 1 < nch) ? cstart + 1 : nch - 1;
+#pragma unroll
+                    for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[c1 * CI_KC + e];
+                }
+#endif
                 __syncthreads();
                 // The history operand of a chunk is loaded and consumed in the same iteration: NO software prefetch.
                 // Measured: hipcc turns every use of a prefetched register into `s_waitcnt vmcnt(0)`, so a register
