@@ -61,6 +61,7 @@ struct medgp_ctx {
     int pin_cur = 0;
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     bool pin_pending[2] = {false, false};
+    char *h_small = nullptr;               // pinned landing area of the host-pointer operator's results (small calls)
     MedgpPrior *d_prior_stage = nullptr;   // device staging of medgp_set_prior[s] rows
     int *d_prior_slots = nullptr;
     size_t prior_stage_rows = 0;
@@ -572,6 +573,7 @@ void medgp_destroy(medgp_ctx *c) {
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_bounce) (void)hipHostFree(c->h_bounce);
+    if (c->h_small) (void)hipHostFree(c->h_small);
     for (int i = 0; i < 2; i++) {
         if (c->pin_buf[i]) (void)hipHostFree(c->pin_buf[i]);
         if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
@@ -920,11 +922,37 @@ int medgp_nlml_grad(medgp_ctx *c, int nbatch, const int32_t *slots, const double
     if (nbatch < 1 || nbatch > c->max_batch) return fail(c, MEDGP_ERR_CAPACITY, "nbatch %d outside [1, %d]", nbatch, c->max_batch);
     HIPCHK(c, hipSetDevice(c->device));
     const size_t H = c->H;
-    HIPCHK(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * nbatch * H, hipMemcpyHostToDevice, c->stream));
+    const bool want_grad = (flag_grad & MEDGP_FLAG_GRAD) != 0;
+    // Small calls (a few patients, the D = 2 configurations): the pageable copies of the runtime cost more than the kernels they
+    // bracket (256 x N=256, D=2: 0.41 ms of kernels, 0.49 ms per call).  Up to 1 MB the arguments travel through pinned memory:
+    // theta through the upload ring, the results into a pinned landing area, one host memcpy each.
+    const size_t th_bytes = sizeof(double) * nbatch * H, out_bytes = sizeof(double) * nbatch * (1 + (want_grad ? H : 0)) + sizeof(int32_t) * nbatch;
+    const size_t kSmall = (size_t)1 << 20;
+    if (th_bytes <= kSmall && out_bytes <= kSmall) {
+        if (!c->h_small) HIPCHK(c, hipHostMalloc((void **)&c->h_small, kSmall + 64, hipHostMallocDefault));
+        void *pin = nullptr;
+        int rcp = pin_stage(c, th_bytes, &pin);
+        if (rcp) return rcp;
+        std::memcpy(pin, theta, th_bytes);
+        HIPCHK(c, hipMemcpyAsync(c->d_theta, pin, th_bytes, hipMemcpyHostToDevice, c->stream));
+        int rc = medgp_nlml_grad_device(c, nbatch, slots, c->d_theta, flag_grad, c->d_nlml, c->d_grad, c->d_status_out);
+        if (rc) return rc;
+        double *hn = (double *)c->h_small, *hg = hn + nbatch;
+        int32_t *hs = (int32_t *)(hg + (want_grad ? (size_t)nbatch * H : 0));
+        HIPCHK(c, hipMemcpyAsync(hn, c->d_nlml, sizeof(double) * nbatch, hipMemcpyDeviceToHost, c->stream));
+        if (want_grad) HIPCHK(c, hipMemcpyAsync(hg, c->d_grad, sizeof(double) * nbatch * H, hipMemcpyDeviceToHost, c->stream));
+        if (status) HIPCHK(c, hipMemcpyAsync(hs, c->d_status_out, sizeof(int32_t) * nbatch, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(nlml, hn, sizeof(double) * nbatch);
+        if (want_grad) std::memcpy(grad, hg, sizeof(double) * nbatch * H);
+        if (status) std::memcpy(status, hs, sizeof(int32_t) * nbatch);
+        return MEDGP_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_theta, theta, th_bytes, hipMemcpyHostToDevice, c->stream));
     int rc = medgp_nlml_grad_device(c, nbatch, slots, c->d_theta, flag_grad, c->d_nlml, c->d_grad, c->d_status_out);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(nlml, c->d_nlml, sizeof(double) * nbatch, hipMemcpyDeviceToHost, c->stream));
-    if (flag_grad & MEDGP_FLAG_GRAD) HIPCHK(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * nbatch * H, hipMemcpyDeviceToHost, c->stream));
+    if (want_grad) HIPCHK(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * nbatch * H, hipMemcpyDeviceToHost, c->stream));
     if (status) HIPCHK(c, hipMemcpyAsync(status, c->d_status_out, sizeof(int32_t) * nbatch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MEDGP_OK;
