@@ -746,6 +746,15 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 __syncthreads();   // init slabs done before Dk (same LDS) is written below
             }
             STAMP(1);
+#ifdef CI_EXP_AHEAD_EMUL   // diagnostic build (results meaningless): the factor runs on wave 0 AFTER the chunk loop of pass 1, beside
+                           // the other waves' panel solve -- prices a look-ahead factor that joins the chunk barriers
+            if (pass == 1 && wave == 0) {
+                // a valid (identity) input: the factor's time does not depend on the data, but a bad pivot would end it early
+                for (int cc = 0; cc < 64; cc++) sm.Dk[lane][cc] = (cc == lane) ? 1.0 : 0.0;
+                __builtin_amdgcn_wave_barrier();
+                diag_factor_wave((ld_t *)&sm.Dk[0][0], (ld_t *)&sm.Xk[0][0], (ld_t *)sm.rhs, (li_t *)&sm.red[8], (ld_t *)&sm.red[0], lane);
+            }
+#endif
             if (pass == 0) {
                 // diagonal block = slot 0 of group 0: every wave of the group holds 16 of its rows
                 if (wg == 0) {
@@ -767,7 +776,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                     for (int w2 = 0; w2 < NW; w2++) zacc += sm.zpart[w2][lane];
                 }
-#ifndef CI_EXP_NOFACTOR   // diagnostic build: factor skipped (results meaningless), prices the factor phase
+#if !defined(CI_EXP_NOFACTOR) && !defined(CI_EXP_AHEAD_EMUL)   // diagnostic builds: factor skipped (results meaningless), prices the factor phase
                 // (k_cholinv<8,2> with the factor inlined and 128 VGPRs -- two 8-wave workgroups per CU, four waves per SIMD --
                 //  was tried: alone it matches <8,4> (0.81 ms at 256 patients), but at 128 VGPRs hipcc spills inside the chunk
                 //  loops and 376 scratch operations into the factor: 2.30 ms at 512 patients against 1.38 ms for <4,4>)
@@ -826,6 +835,9 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
             // ---- triangular solve as GEMM: out^T[ct] = sum_{ct' <= ct} Xk[ct, ct'] acc^T[ct'] on all four units (an
             //      inactive or diagonal unit computes on zeros / unused values: 40 MFMAs, never stored); each 16-column
             //      slab goes through the wave's LDS slab and leaves as whole 128-byte lines
+#ifdef CI_EXP_AHEAD_EMUL
+            if (!(pass == 1 && wave == 0))   // the emulated look-ahead wave owns no units in this pass: no panel solve, no stores
+#endif
             {
 #if CI_SLAB_STORE
                 CI_SLAB_LANE();
