@@ -111,6 +111,24 @@ static_assert(sizeof(CholInvSmem<4, 4>) <= 80 * 1024, "two 4-wave workgroups per
 // Every "-x" that used to feed an MFMA (48 v_xor per pass in the panel solve, 64 in the panel init, the trailing updates of the
 // diagonal factor) is gone: next to the co-resident workgroup's MFMA stream each VALU instruction waits for the pipe.
 #define MFMA_NEGA 1
+// Diagnostic build only (-DCI_EXP_FP32_EMUL, results meaningless, never shipped): TIMING emulation of an fp32 twin of this kernel --
+// the chunk-loop and panel-solve MFMAs become v_mfma_f32_16x16x4_f32 on the low words (same shape, half the cycles), every second
+// history-operand request and half of the staged operand are dropped, half of the panel stores are skipped: the matrix pipe time and
+// the bytes of an fp32 kernel, with this kernel's serial phases and fp64 diagonal factor left as they are.
+#ifdef CI_EXP_FP32_EMUL
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4d mfma_emul32(double a, double b, v4d c) {
+    union { v4d d; v4f f[2]; } u;
+    u.d = c;
+    u.f[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(__double2loint(a)), __int_as_float(__double2loint(b)), u.f[0], 0, 0, 0);
+    return u.d;
+}
+#define CI_MFMA_LOOP(a, b, c) mfma_emul32((a), (b), (c))
+#define CI_MFMA_TRSM(a, b, c) mfma_emul32((a), (b), (c))
+#else
+#define CI_MFMA_LOOP(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, MFMA_NEGA)
+#define CI_MFMA_TRSM(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#endif
 
 __device__ inline double readlane_d(double v, int srclane) {   // srclane must be wave-uniform
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -482,7 +500,11 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
 #define CI_NACT(x) (((x) >= pb[0]) + ((x) >= pb[1]) + ((x) >= pb[2]) + ((x) >= pb[3]))
 // buffer_load with the matrix descriptor in SGPRs, a 32-bit lane offset and a scalar (unit row + chunk) offset: no 64-bit
 // per-lane address arithmetic and no address registers held across the loop (T8 of the guide)
+#ifdef CI_EXP_FP32_EMUL
+#define CI_HLOAD(u, h, cc) { if ((h) == 0) hc[u][h] = ci_bload(rsu[u], voffh + 64 * (h), urow[u] + (cc) * (CI_KC * 8)); }
+#else
 #define CI_HLOAD(u, h, cc) hc[u][h] = ci_bload(rsu[u], voffh + 64 * (h), urow[u] + (cc) * (CI_KC * 8))
+#endif
 // The loop body is straight-line code (the waitcnt pass counts outstanding loads exactly only without branches around
 // them): the requests for chunk c + 1 are unconditional, in the last chunk they re-read that chunk (index clamped) and
 // the result is dropped.  Units that become active at a phase boundary are requested by CI_PHASE_ENTER between the loops.
@@ -501,7 +523,11 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
         _Pragma("unroll") for (int e = 0; e < SPT; e++) bnn[e] = Bsrc[cn2 * CI_KC + e]; }
 #define CI_STAGE_ROTATE() { _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = bnn[e]; }
 #else
+#ifdef CI_EXP_FP32_EMUL
+#define CI_STAGE_LOAD(c, cn) { _Pragma("unroll") for (int e = 0; e < SPT / 2; e++) bnext[e] = Bsrc[(cn) * CI_KC + e]; }
+#else
 #define CI_STAGE_LOAD(c, cn) { _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[(cn) * CI_KC + e]; }
+#endif
 #define CI_STAGE_ROTATE() {}
 #endif
 #define CI_CHUNK_PHASE(NA, lo, hi)                                                                                 \
@@ -517,7 +543,7 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
                 if (hct < 7) a_nxt = *(const v2d *)&sm.Bs[buf][16 * ((hct + 1) & 3) + li][8 * ((hct + 1) >> 2) + 2 * g]; \
                 _Pragma("unroll") for (int s = 0; s < 2; s++)                                                      \
                     _Pragma("unroll") for (int u = 0; u < NA; u++)                                                 \
-                        acc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[s], hc[u][h][s], acc[ct][u], 0, 0, MFMA_NEGA); \
+                        acc[ct][u] = CI_MFMA_LOOP(a_cur[s], hc[u][h][s], acc[ct][u]); \
                 a_cur = a_nxt;                                                                                     \
                 if (ct == 3) {   /* half h is consumed: request it for the next chunk */                           \
                     _Pragma("unroll") for (int u = 0; u < NA; u++) { CI_HLOAD(u, h, cn); }                         \
@@ -776,6 +802,10 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                     for (int w2 = 0; w2 < NW; w2++) zacc += sm.zpart[w2][lane];
                 }
+#ifdef CI_EXP_FP32_EMUL   // the emulated products are garbage: give the (fp64) factor a valid block so that it runs its full course
+                if (wave == 0) { for (int cc = 0; cc < 64; cc++) sm.Dk[lane][cc] = (cc == lane) ? 1.0 : 0.0; }
+                __builtin_amdgcn_wave_barrier();
+#endif
 #if !defined(CI_EXP_NOFACTOR) && !defined(CI_EXP_AHEAD_EMUL)   // diagnostic builds: factor skipped (results meaningless), prices the factor phase
                 // (k_cholinv<8,2> with the factor inlined and 128 VGPRs -- two 8-wave workgroups per CU, four waves per SIMD --
                 //  was tried: alone it matches <8,4> (0.81 ms at 256 patients), but at 128 VGPRs hipcc spills inside the chunk
@@ -857,7 +887,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                         for (int r = 0; r < 4; r++) {
                             double a = sm.Xk[16 * ct + li][16 * cp + 4 * r + g];
 #pragma unroll
-                            for (int u = 0; u < UPW; u++) o[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[cp][u][r], o[u], 0, 0, 0);
+                            for (int u = 0; u < UPW; u++) o[u] = CI_MFMA_TRSM(a, acc[cp][u][r], o[u]);
                         }
 #if CI_SLAB_STORE
 #pragma unroll
@@ -873,7 +903,11 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                     for (int i = 0; i < 2 * UPW; i++) {
                         const int u = i >> 1;
+#ifdef CI_EXP_FP32_EMUL
+                        if (st[u] && !(ct & 1)) {
+#else
                         if (st[u]) {
+#endif
                             gd_t *Out = (isM[u] ? Lb : Ub) + (size_t)(rowb[u] + 8 * (i & 1) + srow8) * ld + c0 + 16 * ct + 2 * spc;
 #ifdef CI_EXP_NOSTORE
                             if (L.ldn < 0)   // diagnostic: never true
