@@ -143,3 +143,42 @@ def test_kde_grid_with_non_finite_point_is_reported():
     grid[1][7] = np.nan
     mode, bw, st, _ = capi.kde_mode(x, False, 0, full=True, test=grid)
     assert st[0] == 0 and mode[0] == ok[0][0] and st[1] == -1 and np.isnan(mode[1])
+
+
+def test_pinned_ring_wraps_without_corrupting_queued_uploads():
+    """The small-upload ring (slot tables, prior rows, theta of small calls) is two pinned buffers of 1 MB: several thousand
+    queued uploads force it to wrap many times while earlier copies may still be in flight.  Alternating prior sets and slot
+    lists must always be evaluated with the values of THEIR call."""
+    import torch
+    P, D, Q, R = 12, 3, 3, 2
+    ctx, pts, th = _ctx(P, D, 70, Q, R)
+    H = ctx.H
+    f, ty, ex, p0, p1 = synth.hier_gamma_prior(Q, D, R, 0.01)
+    sets = []
+    for v in (0.5, 2.0):
+        q1 = p1.copy()
+        q1[D:D + Q * D * R] = np.float32(v)
+        sets.append([np.stack([a] * P) for a in (f, ty, ex, p0, q1)])
+    ref = []
+    for k in range(2):
+        ctx.set_priors(np.arange(P), *sets[k])
+        ref.append(ctx.nlml_grad(np.arange(P), th, False)[0])
+    assert not np.array_equal(ref[0], ref[1])
+    dev = torch.device("cuda", 0)
+    th_d = torch.from_numpy(th).to(dev)
+    outs = []
+    row_bytes = P * H * 12
+    ncalls = int(3 * (2 << 20) / row_bytes) + 8          # > three full revolutions of the ring
+    for it in range(ncalls):
+        k = it & 1
+        ctx.set_priors(np.arange(P), *sets[k])            # queued, no device wait
+        if it % 16 == 0:
+            nl = torch.empty(P, dtype=torch.float64, device=dev)
+            ctx.nlml_grad_device(np.arange(P), th_d.data_ptr(), 0, nl.data_ptr(), 0, 0)
+            outs.append((k, nl))
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    assert len(outs) > 20
+    for k, nl in outs:
+        assert np.array_equal(nl.cpu().numpy(), ref[k])
+    ctx.close()
