@@ -670,7 +670,11 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 bool ldu[UPW], anyld = false;
 #pragma unroll
                 for (int u = 0; u < UPW; u++) { ldu[u] = act[u] && isM[u]; anyld = anyld || ldu[u]; }
+#ifdef CI_EXP_NOINIT   // diagnostic build (results meaningless): prices the panel init (K-block loads + LDS transposition)
+                if (false) {
+#else
                 if (anyld) {   // branch-free inside: units without a K block read the block of slot 0 and discard it
+#endif
                     // all 64 columns are requested at once (the registers the accumulators will occupy are free here): one
                     // memory round trip per pass instead of one per 32-column half
                     v2d kin[4][2 * UPW];
@@ -802,7 +806,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                     for (int w2 = 0; w2 < NW; w2++) zacc += sm.zpart[w2][lane];
                 }
-#ifdef CI_EXP_FP32_EMUL   // the emulated products are garbage: give the (fp64) factor a valid block so that it runs its full course
+#if defined(CI_EXP_FP32_EMUL) || defined(CI_EXP_NOINIT) || defined(CI_EXP_NOTRSM)   // diagnostic builds with garbage products: give the (fp64) factor a valid block so that it runs its full course
                 if (wave == 0) { for (int cc = 0; cc < 64; cc++) sm.Dk[lane][cc] = (cc == lane) ? 1.0 : 0.0; }
                 __builtin_amdgcn_wave_barrier();
 #endif
@@ -867,6 +871,9 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
             //      slab goes through the wave's LDS slab and leaves as whole 128-byte lines
 #ifdef CI_EXP_AHEAD_EMUL
             if (!(pass == 1 && wave == 0))   // the emulated look-ahead wave owns no units in this pass: no panel solve, no stores
+#endif
+#ifdef CI_EXP_NOTRSM   // diagnostic build (results meaningless): prices the panel solve + stores
+            if (L.ldn < 0)
 #endif
             {
 #if CI_SLAB_STORE
