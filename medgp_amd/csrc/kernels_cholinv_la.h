@@ -48,6 +48,8 @@ struct LaArgs {
     int nbmax;            // 64-blocks of the largest patient of the batch
     int maxslice;         // slices per row block the scratch is dimensioned for
     int rows;             // row blocks the scratch is dimensioned for (2 nbmax + 1)
+    int ring;             // index mask of the chain's hand-off slabs xk2 / pnx / dterm / dsum: 1 = by parity (one launch per step);
+                          // 2^m - 1 >= nbmax = one slab per step (persistent schedule: nothing is overwritten inside the launch)
 };
 
 // row block index inside the scratch: M_i -> i, U_rho -> nbmax + rho, Y -> 2 nbmax
@@ -181,7 +183,7 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
         }
         if (cb == 0 && nb > 1) {
             const double *K10 = L.Kmat + (size_t)b * ld * ld + (size_t)64 * ld;
-            double *Pn = A.pnx + ((size_t)b * 2 + 0) * 4096;
+            double *Pn = A.pnx + ((size_t)b * (A.ring + 1) + 0) * 4096;
             for (int e = tid; e < 64 * 64; e += LA_THREADS) Pn[e] = K10[(size_t)(e >> 6) * ld + (e & 63)];
         }
         return;
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
     diag_factor_wg((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.Ls[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, w, lane);
     __syncthreads();
     if (sm.fail) { if (tid == 0) L.status[b] = -2; return; }
-    double *Xg = A.xk2 + ((size_t)b * 2 + 0) * 4096;
+    double *Xg = A.xk2 + ((size_t)b * (A.ring + 1) + 0) * 4096;
     for (int e = tid; e < 64 * 64; e += LA_THREADS) {
         const int rr = e >> 6, cc = e & 63;
         if (cc <= rr) Lb[(size_t)rr * ld + cc] = sm.Xs[rr][cc];
@@ -231,83 +233,97 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
 #define LA_T0() do {} while (0)
 #define LA_TEND(role) do {} while (0)
 #endif
-// park >= 0 (single-entry calls): the workgroup with blockIdx.y == park does no work -- it keeps its slot (its LDS) until the
-// diagonal chain of this step is done.  Workgroup 0 (the chain) is dispatched first and lands on the first CU of XCD 0; once every
-// CU holds one workgroup, the next one dispatched to that XCD (id 256) is placed on the same CU, and from then on a bulk (L / F)
-// workgroup shares the chain's CU and its fp64 pipe: the chain slows from 63 k to 82-97 k cycles.  Parked there, a sleeping
-// workgroup costs one of 512 slots and nothing else; if the placement guess is wrong it is merely a wasted slot.  It waits on a
-// flag with a bounded number of polls (no way to hang).
-__global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A, int k, int want_mode, int nLrowsL, int park) {
-    __shared__ LaSmem sm;
-    LA_T0();
-    const int b = blockIdx.x;
-    const int st0 = L.status[b], n0 = L.bn[b];      // two independent loads (bslot -> pn would be a dependent chain of three)
-    if (st0 < 0) return;
-    const int n = __builtin_amdgcn_readfirstlane(n0);
-    const int ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
-    if (k >= nb || nb < 2) return;
-    if (park >= 0 && (int)blockIdx.y == park) {
-        if (threadIdx.x >= 64 || k + 1 >= nb) return;   // one wave holds the slot; the last step has no chain
-        for (int it = 0; it < 2000; it++) {              // <= ~3 ms, far beyond any step
-            if (__hip_atomic_load(&A.flag[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > k) break;
-            __builtin_amdgcn_s_sleep(64);
-        }
-        return;
-    }
-    const int want_inv = want_mode & 1;
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *Lb = L.Kmat + (size_t)b * ld * ld, *Ub = L.Linv + (size_t)b * ld * ld;
-    const int c0 = 64 * k, c1 = 64 * (k + 1);
-    const bool has_next = (k + 1 < nb);
-    int task = (park >= 0 && (int)blockIdx.y > park) ? (int)blockIdx.y - 1 : (int)blockIdx.y;
+// One task of step k (the body of k_la_step, shared with the persistent schedule of kernels_cholinv_lp.h).
+// PERSIST = false: one launch per step, every operand was final before the launch, plain stores.
+// PERSIST = true:  the task runs inside ONE launch next to its producers and consumers (other workgroups, other XCDs): every
+//                  byte another workgroup reads later is stored write-through (sc1: la_st), the caller polls the task's
+//                  dependencies, acquires, and publishes the task's completion afterwards; the ring indices of the chain's
+//                  hand-off slabs (xk2, pnx, dterm, dsum) are the step itself instead of its parity (LaArgs::ring).
+struct LaTask {
+    int role;             // 0 = D (diagonal chain), 1 = F, 2 = L (look-ahead), 3 = R
+    LaRow row;
+    int slice;
+    bool diag_ahead;
+};
+template <bool PERSIST> __device__ __forceinline__ void la_st(double *p, double v) {
+    if constexpr (PERSIST) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store_dwordx2 sc1
+    else *p = v;
+}
+template <bool PERSIST> __device__ __forceinline__ void la_store_tp(double *blk, int ld, const v4d (&o)[4], int li, int g) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) la_st<PERSIST>(&blk[(size_t)li * ld + 16 * ct + 4 * r + g], o[ct][r]);
+}
+// slab index of a chain hand-off buffer for step / block x
+__device__ __forceinline__ int la_ring(const LaArgs &A, int x) { return x & A.ring; }
+
+// task index of a step's list (0 = D, 1 .. nF = F, nF + 1 = R, then the L tasks slice-major) -> role; false: empty slot
+__device__ __forceinline__ bool la_decode(const LaArgs &A, int k, int want_inv, int task, int nLrowsL, LaTask &T) {
     // the task lists are laid out for the largest patient of the batch (A.nbmax)
     const int nM_F = A.nbmax - (k + 2) > 0 ? A.nbmax - (k + 2) : 0;
     const int nU_F = want_inv ? k + 1 : 0;
     const int nF = nM_F + nU_F + 1;
-    LaRow row;
-    int role, slice = 0;
-    bool diag_ahead = false;
-    if (task == 0) { role = 0; row.kind = 0; row.blk = k + 1; }
+    T.slice = 0;
+    T.diag_ahead = false;
+    if (task == 0) { T.role = 0; T.row.kind = 0; T.row.blk = k + 1; }
     else if (task <= nF) {
-        role = 1;
+        T.role = 1;
         int t = task - 1;
-        if (t < nM_F) { row.kind = 0; row.blk = k + 2 + t; }
-        else if (t < nM_F + nU_F) { row.kind = 1; row.blk = t - nM_F; }
-        else { row.kind = 2; row.blk = 0; }
+        if (t < nM_F) { T.row.kind = 0; T.row.blk = k + 2 + t; }
+        else if (t < nM_F + nU_F) { T.row.kind = 1; T.row.blk = t - nM_F; }
+        else { T.row.kind = 2; T.row.blk = 0; }
     } else if (task == nF + 1) {
-        role = 3; row.kind = 0; row.blk = k + 2;   // R: sum of the diagonal look-ahead slices of block k+2
+        T.role = 3; T.row.kind = 0; T.row.blk = k + 2;   // R: sum of the diagonal look-ahead slices of block k+2
     } else {
-        role = 2;
+        T.role = 2;
         // slice-major, and only the ceil(k / LA_SLICE) slices that exist at this step are launched: the L tasks that have work
         // are then consecutive in dispatch order, which the hardware deals round-robin over the 8 XCDs.  (Row-major over
         // maxslice slots per row put the live tasks -- slices 0, 1 of every row early on -- at ids = 0, 1 mod 16, i.e. on TWO
         // of the eight XCDs, behind ~850 empty workgroups: at N = 4096 the L role ended at 49 us of a step whose diagonal
         // chain needs 34 us.)
         int t = task - 2 - nF;
-        slice = t / nLrowsL;
-        t -= slice * nLrowsL;
-        if (slice >= A.maxslice) return;
+        T.slice = t / nLrowsL;
+        t -= T.slice * nLrowsL;
+        if (T.slice >= A.maxslice) return false;
         const int nU_L = want_inv ? k : 0;
         // slot 0 of every slice used to be row M_k+2 of panel k+2 -- the NEXT diagonal block, consumed by the chain alone.  The chain
         // now gets its block ready-made (diagonal head start), so the slot instead looks one block further ahead: partial sums of
         // the diagonal block k+3 (rows of block k+3 times themselves) over the same history slice, summed by the F workgroup of that
         // row block in the next launch -- off the chain.
-        diag_ahead = (t == 0 && nM_F >= 1);
-        if (diag_ahead) { row.kind = 0; row.blk = k + 3; }
-        else if (t < nM_F) { row.kind = 0; row.blk = k + 2 + t; }
-        else if (t < nM_F + nU_L) { row.kind = 1; row.blk = t - nM_F; }
-        else if (t == nM_F + nU_L) { row.kind = 2; row.blk = 0; }
-        else return;
+        T.diag_ahead = (t == 0 && nM_F >= 1);
+        if (T.diag_ahead) { T.row.kind = 0; T.row.blk = k + 3; }
+        else if (t < nM_F) { T.row.kind = 0; T.row.blk = k + 2 + t; }
+        else if (t < nM_F + nU_L) { T.row.kind = 1; T.row.blk = t - nM_F; }
+        else if (t == nM_F + nU_L) { T.row.kind = 2; T.row.blk = 0; }
+        else return false;
     }
-    if (row.kind == 0 && row.blk >= nb && !(role == 0)) return;   // beyond this patient's blocks
+    return true;
+}
+
+// returns 1 when the D role met a non-positive pivot (status -2 is set by the caller's protocol), else 0
+template <bool PERSIST>
+__device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSmem &sm, int b, int n, int k, int want_mode, const LaTask &T) {
+    LA_T0();
+    const int ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
+    const int want_inv = want_mode & 1;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *Lb = L.Kmat + (size_t)b * ld * ld, *Ub = L.Linv + (size_t)b * ld * ld;
+    const int c0 = 64 * k, c1 = 64 * (k + 1);
+    const bool has_next = (k + 1 < nb);
+    const int role = T.role, slice = T.slice;
+    const LaRow row = T.row;
+    const bool diag_ahead = T.diag_ahead;
+    (void)want_inv;
+    if (row.kind == 0 && row.blk >= nb && !(role == 0)) return 0;   // beyond this patient's blocks
     double *Rb = la_row_base(L, A, b, row);
 
     // ============================== R: diagonal look-ahead slices of block k+2 -> one slab ===============================
     // (slices over panels 0 .. k-2, written by the diag-ahead L tasks of the previous launch; read by the chain of the next launch
     //  together with A.dterm.  All loads of a group of four slices are independent; fixed summation order.)
     if (role == 3) {
-        if (k + 2 >= nb) return;
+        if (k + 2 >= nb) return 0;
         const int nsd = (k >= 2) ? (k - 1 + LA_SLICE - 1) / LA_SLICE : 0;
         const double *Dp = A.dpart + (((size_t)b * 2 + ((k + 2) & 1)) * A.maxslice) * 4096 + (size_t)w * 1024 + lane;
         double sacc[16];
@@ -329,19 +345,19 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
 #pragma unroll
             for (int e = 0; e < 16; e++) sacc[e] += Dp[(size_t)sd * 4096 + e * 64];
         }
-        double *Ds = A.dsum + ((size_t)b * 2 + ((k + 2) & 1)) * 4096 + (size_t)w * 1024 + lane;
+        double *Ds = A.dsum + ((size_t)b * (A.ring + 1) + la_ring(A, k + 2)) * 4096 + (size_t)w * 1024 + lane;
 #pragma unroll
-        for (int e = 0; e < 16; e++) Ds[e * 64] = sacc[e];
-        return;
+        for (int e = 0; e < 16; e++) la_st<PERSIST>(&Ds[e * 64], sacc[e]);
+        return 0;
     }
 
     // ============================== L: look-ahead partial sum of panel k+2 =============================================
     if (role == 2) {
-        if (k + 2 >= nb) return;
+        if (k + 2 >= nb) return 0;
         const int j0 = la_first_panel(row) + LA_SLICE * slice;
         int j1 = j0 + LA_SLICE;
         if (j1 > k) j1 = k;                       // history panels <= k-1
-        if (j0 >= j1) return;
+        if (j0 >= j1) return 0;
         v4d acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ct++) acc[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -352,15 +368,15 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
 #pragma unroll
         for (int ct = 0; ct < 4; ct++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) P[(ct * 4 + r) * 64] = acc[ct][r];
+            for (int r = 0; r < 4; r++) la_st<PERSIST>(&P[(ct * 4 + r) * 64], acc[ct][r]);
         LA_TEND(2);
-        return;
+        return 0;
     }
 
     // ============================== D and F ============================================================================
-    const double *Xg = A.xk2 + ((size_t)b * 2 + (k & 1)) * 4096;
+    const double *Xg = A.xk2 + ((size_t)b * (A.ring + 1) + la_ring(A, k)) * 4096;
     const bool is_D = (role == 0);
-    if (is_D && !has_next) return;                // the last panel has no next diagonal block
+    if (is_D && !has_next) return 0;                // the last panel has no next diagonal block
 #ifdef LA_STAMPS_ABS
     if (is_D && threadIdx.x == 0) ((unsigned long long *)L.slab)[8 * k + 5] = la_t0;   // the chain's own start (wall clock)
 #endif
@@ -374,7 +390,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
 #pragma unroll
     for (int e = 0; e < 8; e++) xreg[e] = *(const v2d *)(Xg + 2 * (tid + LA_THREADS * e));
     v4d pval[4];
-    if (has_next) la_load_t(A.pnx + ((size_t)b * 2 + (k & 1)) * 4096 + (size_t)(16 * w) * 64, 64, pval, li, g);
+    if (has_next) la_load_t(A.pnx + ((size_t)b * (A.ring + 1) + la_ring(A, k)) * 4096 + (size_t)(16 * w) * 64, 64, pval, li, g);
     double *oblk = Rb + (size_t)(16 * w) * ld + c0;   // the role's own block of panel k: read at its use (F roles are not on
                                                       // the critical path; holding it from here cost the kernel its second
                                                       // workgroup per CU)
@@ -390,8 +406,8 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     const bool head_start = is_D && k >= 1;
     if (has_next) {
         if (head_start) {
-            const double *Dt = A.dterm + ((size_t)b * 2 + ((k + 1) & 1)) * 4096 + (size_t)w * 1024 + lane;
-            const double *Ds = A.dsum + ((size_t)b * 2 + ((k + 1) & 1)) * 4096 + (size_t)w * 1024 + lane;
+            const double *Dt = A.dterm + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096 + (size_t)w * 1024 + lane;
+            const double *Ds = A.dsum + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096 + (size_t)w * 1024 + lane;
             double dtv[16], dsv[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) dtv[e] = Dt[e * 64];
@@ -444,7 +460,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
         for (int ct = 0; ct < 4; ct++)
 #pragma unroll
             for (int r = 0; r < 4; r++) sm.Ls[16 * w + li][16 * ct + 4 * r + g] = o[ct][r];
-        if (is_D) la_store_t(Lb + (size_t)(c1 + 16 * w) * ld + c0, ld, o, li, g);   // final L[C_k+1, C_k]
+        if (is_D) la_store_tp<PERSIST>(Lb + (size_t)(c1 + 16 * w) * ld + c0, ld, o, li, g);   // final L[C_k+1, C_k]
     }
     // ---- (4) own rows of panel k: row_r[C_k] = P_r,k X_k^T   (D: that is the block above, already in o;  U_k: the
     //      diagonal block U_kk itself, final since the previous launch)
@@ -454,10 +470,10 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
             v4d oval[4];
             la_load_t(oblk, ld, oval, li, g);
             la_trsm(sm.Xs, oval, o, li, g);
-            la_store_t(oblk, ld, o, li, g);
+            la_store_tp<PERSIST>(oblk, ld, o, li, g);
         }
     }
-    if (!has_next) { LA_TEND(1); return; }
+    if (!has_next) { LA_TEND(1); return 0; }
     __syncthreads();   // Ls complete
     LA_TD(4);
     // ---- (5) newest rank-64 term: acc += row_r[C_k] L[C_k+1,C_k]^T, straight from the trsm registers (A operand)
@@ -475,13 +491,13 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
 #pragma unroll
         for (int ct = 0; ct < 4; ct++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) Rb[(size_t)(16 * w + 4 * r + g) * ld + c1 + 16 * ct + li] = -acc[ct][r];
+            for (int r = 0; r < 4; r++) la_st<PERSIST>(&Rb[(size_t)(16 * w + 4 * r + g) * ld + c1 + 16 * ct + li], -acc[ct][r]);
         if (row.kind == 0 && row.blk == k + 2) {   // next step's P_k+2,k+1: everybody reads this copy
-            double *Pn = A.pnx + ((size_t)b * 2 + ((k + 1) & 1)) * 4096;
+            double *Pn = A.pnx + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096;
 #pragma unroll
             for (int ct = 0; ct < 4; ct++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) Pn[(16 * w + 4 * r + g) * 64 + 16 * ct + li] = -acc[ct][r];
+                for (int r = 0; r < 4; r++) la_st<PERSIST>(&Pn[(16 * w + 4 * r + g) * 64 + 16 * ct + li], -acc[ct][r]);
             // diagonal head start for the NEXT launch's chain (row block k+2 is its D role):  -K[k+2, k+2] + row[C_k] row[C_k]^T,
             // this workgroup's 64 rows of panel k (o, final) times themselves.  X_k in Xs is dead (every wave passed the barrier
             // after its trsm), so the rows go there as the shared operand; acc is free again.
@@ -508,12 +524,12 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
             // the longest task of the launch at N = 4096)
             __syncthreads();   // the rows in Xs have been read: la_gemm stages through the same LDS
             if (k >= 1) la_gemm(Rb, Lb + (size_t)c2 * ld, ld, k - 1, k, acc, sm, tid, w, li, g);
-            double *Dt = A.dterm + ((size_t)b * 2 + ((k + 2) & 1)) * 4096 + (size_t)w * 1024 + lane;
+            double *Dt = A.dterm + ((size_t)b * (A.ring + 1) + la_ring(A, k + 2)) * 4096 + (size_t)w * 1024 + lane;
 #pragma unroll
-            for (int e = 0; e < 16; e++) Dt[e * 64] = acc[e >> 2][e & 3];
+            for (int e = 0; e < 16; e++) la_st<PERSIST>(&Dt[e * 64], acc[e >> 2][e & 3]);
         }
         LA_TEND(1);
-        return;
+        return 0;
     }
     LA_TD(5);
     // ---- (6) D: factor the next diagonal block
@@ -527,19 +543,49 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     diag_factor_wg((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.Ls[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, w, lane);
     __syncthreads();
     LA_TD(6);
-    if (sm.fail) { if (tid == 0) { L.status[b] = -2; __hip_atomic_store(&A.flag[b], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
-    double *Xn = A.xk2 + ((size_t)b * 2 + ((k + 1) & 1)) * 4096;
+    if (sm.fail) return 1;
+    double *Xn = A.xk2 + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096;
     for (int e = tid; e < 64 * 64; e += LA_THREADS) {
         const int rr = e >> 6, cc = e & 63;
-        if (cc <= rr) Lb[(size_t)(c1 + rr) * ld + c1 + cc] = sm.Xs[rr][cc];
-        if (want_mode) Ub[(size_t)(c1 + rr) * ld + c1 + cc] = (cc >= rr) ? sm.Ls[cc][rr] : 0.0;
-        Xn[e] = sm.Ls[rr][cc];
+        if (cc <= rr) la_st<PERSIST>(&Lb[(size_t)(c1 + rr) * ld + c1 + cc], sm.Xs[rr][cc]);
+        if (want_mode) la_st<PERSIST>(&Ub[(size_t)(c1 + rr) * ld + c1 + cc], (cc >= rr) ? sm.Ls[cc][rr] : 0.0);
+        la_st<PERSIST>(&Xn[e], sm.Ls[rr][cc]);
     }
-    if (tid == 0) {
-        L.scal[b * 4 + 0] += sm.logdet;   // steps are ordered launches: fixed summation order
+    if (tid == 0) L.scal[b * 4 + 0] += sm.logdet;   // the chain's steps are ordered: fixed summation order
+    LA_TEND(0);
+    return 0;
+}
+
+// park >= 0 (single-entry calls): the workgroup with blockIdx.y == park does no work -- it keeps its slot (its LDS) until the
+// diagonal chain of this step is done.  Workgroup 0 (the chain) is dispatched first and lands on the first CU of XCD 0; once every
+// CU holds one workgroup, the next one dispatched to that XCD (id 256) is placed on the same CU, and from then on a bulk (L / F)
+// workgroup shares the chain's CU and its fp64 pipe: the chain slows from 63 k to 82-97 k cycles.  Parked there, a sleeping
+// workgroup costs one of 512 slots and nothing else; if the placement guess is wrong it is merely a wasted slot.  It waits on a
+// flag with a bounded number of polls (no way to hang).
+__global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A, int k, int want_mode, int nLrowsL, int park) {
+    __shared__ LaSmem sm;
+    const int b = blockIdx.x;
+    const int st0 = L.status[b], n0 = L.bn[b];      // two independent loads (bslot -> pn would be a dependent chain of three)
+    if (st0 < 0) return;
+    const int n = __builtin_amdgcn_readfirstlane(n0);
+    const int nb = medgp_roundup(n, 64) / 64;
+    if (k >= nb || nb < 2) return;
+    if (park >= 0 && (int)blockIdx.y == park) {
+        if (threadIdx.x >= 64 || k + 1 >= nb) return;   // one wave holds the slot; the last step has no chain
+        for (int it = 0; it < 2000; it++) {              // <= ~3 ms, far beyond any step
+            if (__hip_atomic_load(&A.flag[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > k) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+        return;
+    }
+    const int task = (park >= 0 && (int)blockIdx.y > park) ? (int)blockIdx.y - 1 : (int)blockIdx.y;
+    LaTask T;
+    if (!la_decode(A, k, want_mode & 1, task, nLrowsL, T)) return;
+    const int failed = la_body<false>(L, A, sm, b, n, k, want_mode, T);
+    if (T.role == 0 && k + 1 < nb && threadIdx.x == 0) {
+        if (failed) L.status[b] = -2;
         __hip_atomic_store(&A.flag[b], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // releases the parked workgroup
     }
-    LA_TEND(0);
 }
 
 // ---- epilogue of the factorisation: z, quad = z^T z, alpha = U z, status = jitter count -----------------------------------
