@@ -29,6 +29,12 @@
 #define LA_THREADS 256
 #define LA_SLICE 4        // panels (64 columns each) per look-ahead slice
 #define LA_S 66           // LDS row stride of the 64x64 operand tiles
+#ifndef LA_F_LATE
+#define LA_F_LATE 0       // 1: F tasks request X_k / the pre-solve copy after their partial sums instead of up front
+#endif
+#ifndef LA_NSUM
+#define LA_NSUM 3         // partial-sum slabs an F task requests per memory round trip
+#endif
 
 struct LaArgs {
     double *ybuf;         // [batch][64][ldn]   the Y row block (row 0 = y^T -> z^T)
@@ -94,15 +100,17 @@ __device__ __forceinline__ void la_gemm(const double *Hist, const double *Bpanel
     if (nch <= 0) return;
     const int kstart = 64 * j0;
     const double *Arow = Hist + (size_t)(16 * w + li) * ld + kstart + 2 * g;
-    const int srow = tid >> 2, scg = (tid & 3) * 8;
-    const double *Bsrc = Bpanel + (size_t)srow * ld + kstart + scg;
+    // staging of the shared operand: a wave instruction covers 4 rows x 256 contiguous bytes (whole 128-byte lines; the former
+    // 16 rows x 4 x 16 bytes at a 64-byte stride touched 32 lines per instruction)
+    const int srow = tid >> 4, scol = (tid & 15) * 2;
+    const double *Bsrc = Bpanel + (size_t)srow * ld + kstart + scol;
     v2d bst[4], an[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) bst[u] = *(const v2d *)(Bsrc + 2 * u);
+    for (int u = 0; u < 4; u++) bst[u] = *(const v2d *)(Bsrc + (size_t)(16 * u) * ld);
 #pragma unroll
     for (int h = 0; h < 4; h++) an[h] = *(const v2d *)(Arow + 8 * h);
 #pragma unroll
-    for (int u = 0; u < 4; u++) *(v2d *)&sm.Bs[0][srow][scg + 2 * u] = bst[u];
+    for (int u = 0; u < 4; u++) *(v2d *)&sm.Bs[0][srow + 16 * u][scol] = bst[u];
     __syncthreads();
     for (int c = 0; c < nch; c++) {
         const int buf = c & 1;
@@ -111,7 +119,7 @@ __device__ __forceinline__ void la_gemm(const double *Hist, const double *Bpanel
         for (int h = 0; h < 4; h++) ac[h] = an[h];
         if (c + 1 < nch) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) bst[u] = *(const v2d *)(Bsrc + (c + 1) * LA_KC + 2 * u);
+            for (int u = 0; u < 4; u++) bst[u] = *(const v2d *)(Bsrc + (size_t)(16 * u) * ld + (c + 1) * LA_KC);
 #pragma unroll
             for (int h = 0; h < 4; h++) an[h] = *(const v2d *)(Arow + (c + 1) * LA_KC + 8 * h);
         }
@@ -128,7 +136,7 @@ __device__ __forceinline__ void la_gemm(const double *Hist, const double *Bpanel
         }
         if (c + 1 < nch) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) *(v2d *)&sm.Bs[buf ^ 1][srow][scg + 2 * u] = bst[u];
+            for (int u = 0; u < 4; u++) *(v2d *)&sm.Bs[buf ^ 1][srow + 16 * u][scol] = bst[u];
         }
         __syncthreads();
     }
@@ -228,7 +236,9 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
 #else
 #define LA_TD(slot) do { if (is_D && threadIdx.x == 0) ((unsigned long long *)L.slab)[8 * k + (slot)] = __builtin_amdgcn_s_memtime() - la_t0; } while (0)
 #endif
+#define LA_TF(slot) do { if (role == 1 && row.kind == 0 && (row.blk == k + 2 || row.blk == k + 3) && threadIdx.x == 0) ((unsigned long long *)L.slab)[640 + 16 * k + 8 * (row.blk - k - 2) + (slot)] = __builtin_amdgcn_s_memtime() - la_t0; } while (0)
 #else
+#define LA_TF(slot) do {} while (0)
 #define LA_TD(slot) do {} while (0)
 #define LA_T0() do {} while (0)
 #define LA_TEND(role) do {} while (0)
@@ -248,6 +258,10 @@ struct LaTask {
 template <bool PERSIST> __device__ __forceinline__ void la_st(double *p, double v) {
     if constexpr (PERSIST) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store_dwordx2 sc1
     else *p = v;
+}
+template <bool PERSIST> __device__ __forceinline__ void la_st2(double *p, v2d v) {   // 16-byte aligned pair
+    if constexpr (PERSIST) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else *(v2d *)p = v;
 }
 template <bool PERSIST> __device__ __forceinline__ void la_store_tp(double *blk, int ld, const v4d (&o)[4], int li, int g) {
 #pragma unroll
@@ -303,21 +317,46 @@ __device__ __forceinline__ bool la_decode(const LaArgs &A, int k, int want_inv, 
 
 // returns 1 when the D role met a non-positive pivot (status -2 is set by the caller's protocol), else 0
 template <bool PERSIST>
-__device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSmem &sm, int b, int n, int k, int want_mode, const LaTask &T) {
+__device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSmem &sm, int b, int n_in, int k, int want_mode, const LaTask &T) {
     LA_T0();
-    const int ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
-    const int want_inv = want_mode & 1;
+    const int ld = L.ldn;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *Lb = L.Kmat + (size_t)b * ld * ld, *Ub = L.Linv + (size_t)b * ld * ld;
-    const int c0 = 64 * k, c1 = 64 * (k + 1);
-    const bool has_next = (k + 1 < nb);
     const int role = T.role, slice = T.slice;
     const LaRow row = T.row;
     const bool diag_ahead = T.diag_ahead;
+    const bool is_D = (role == 0);
+    // ---- (0) D and F: every global operand whose address depends on (entry, step) alone is requested before anything else -- X_k, the
+    //      pre-solve copy P_k+1,k, the chain's head-start slabs -- and the entry's status / size words travel WITH them: one memory
+    //      round trip at the head of the step's critical path instead of two dependent ones (the slabs exist for every step of
+    //      the schedule, so the requests are valid whatever the patient's size turns out to be)
+    const double *Xg = A.xk2 + ((size_t)b * (A.ring + 1) + la_ring(A, k)) * 4096;
+    v2d xreg[8];
+    v4d pval[4];
+    const bool head_start = is_D && k >= 1;
+    v4d acc[4];           // pre-solve block of panel k+1 (non-transposed tiles); the chain's head start lands here directly
+    double dsv[16];
+    if (role <= 1 && (is_D || !LA_F_LATE)) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) xreg[e] = *(const v2d *)(Xg + 2 * (tid + LA_THREADS * e));
+        la_load_t(A.pnx + ((size_t)b * (A.ring + 1) + la_ring(A, k)) * 4096 + (size_t)(16 * w) * 64, 64, pval, li, g);
+    }
+    int n = n_in;
+    if (n_in < 0) {
+        const int st0 = L.status[b], n0 = L.bn[b];      // two independent loads (bslot -> pn would be a dependent chain of three)
+        if (st0 < 0) return 0;
+        n = __builtin_amdgcn_readfirstlane(n0);
+    }
+    const int npad = medgp_roundup(n, 64), nb = npad / 64;
+    if (k >= nb || nb < 2) return 0;
+    const int want_inv = want_mode & 1;
+    double *Lb = L.Kmat + (size_t)b * ld * ld, *Ub = L.Linv + (size_t)b * ld * ld;
+    const int c0 = 64 * k, c1 = 64 * (k + 1);
+    const bool has_next = (k + 1 < nb);
     (void)want_inv;
     if (row.kind == 0 && row.blk >= nb && !(role == 0)) return 0;   // beyond this patient's blocks
     double *Rb = la_row_base(L, A, b, row);
+    LA_TF(0);
 
     // ============================== R: diagonal look-ahead slices of block k+2 -> one slab ===============================
     // (slices over panels 0 .. k-2, written by the diag-ahead L tasks of the previous launch; read by the chain of the next launch
@@ -374,8 +413,6 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     }
 
     // ============================== D and F ============================================================================
-    const double *Xg = A.xk2 + ((size_t)b * (A.ring + 1) + la_ring(A, k)) * 4096;
-    const bool is_D = (role == 0);
     if (is_D && !has_next) return 0;                // the last panel has no next diagonal block
 #ifdef LA_STAMPS_ABS
     if (is_D && threadIdx.x == 0) ((unsigned long long *)L.slab)[8 * k + 5] = la_t0;   // the chain's own start (wall clock)
@@ -383,38 +420,28 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     // (s_setprio 3 for the diagonal chain, which shares its CU with a bulk workgroup once the chip is full: measured, no effect --
     //  the chain's cycle count does not change with the load, the shader clock does: 71 k cycles take 29.7 us early and 37.5 us
     //  from step 16 of N = 4096 on, when more than 256 L workgroups run fp64 MFMA)
-    // ---- (0) every global operand of this role is requested up front (X_k, the pre-solve copy P_k+1,k, the role's own block
-    //      of panel k, the initial block of panel k+1): one memory round trip instead of four dependent ones on the
-    //      critical path of the step; the history product below hides it
-    v2d xreg[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) xreg[e] = *(const v2d *)(Xg + 2 * (tid + LA_THREADS * e));
-    v4d pval[4];
-    if (has_next) la_load_t(A.pnx + ((size_t)b * (A.ring + 1) + la_ring(A, k)) * 4096 + (size_t)(16 * w) * 64, 64, pval, li, g);
     double *oblk = Rb + (size_t)(16 * w) * ld + c0;   // the role's own block of panel k: read at its use (F roles are not on
                                                       // the critical path; holding it from here cost the kernel its second
                                                       // workgroup per CU)
     // ---- (1) pre-solve block of panel k+1: acc = -init + partials + term of panel k-1     (non-transposed tiles)
-    v4d acc[4];
+    if (!head_start) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) acc[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int ct = 0; ct < 4; ct++) acc[ct] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
     const int jf = la_first_panel(row);
     // Diagonal head start (D role, k >= 1): the F workgroup of row block k+1 left  -K[k+1, k+1] + sum_{j <= k-1} row[C_j] row[C_j]^T
     // in A.dterm during the previous launch (panel k-1 from its registers, panel k-2 as a 64 x 64 x 64 product, everything older
     // from the diagonal look-ahead slices A.dpart), so the chain neither loads its initial block, nor walks the chain of partial-sum
     // round trips (0.9 us per two slices, up to 15 slices at N = 4096), nor runs the product of panel k-1.
-    const bool head_start = is_D && k >= 1;
     if (has_next) {
         if (head_start) {
             const double *Dt = A.dterm + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096 + (size_t)w * 1024 + lane;
             const double *Ds = A.dsum + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096 + (size_t)w * 1024 + lane;
-            double dtv[16], dsv[16];
 #pragma unroll
-            for (int e = 0; e < 16; e++) dtv[e] = Dt[e * 64];
+            for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] = Dt[e * 64];
 #pragma unroll
             for (int e = 0; e < 16; e++) dsv[e] = Ds[e * 64];     // (written by the R workgroup of the previous launch, k >= 1: zeros when there were no slices)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] = dtv[e] + dsv[e];
+            // (the two slabs are added in front of step (5): their round trip runs under the solve)
         } else if (row.kind != 1) {   // K rows and the y row carry their own initial values in place; U rows start from zero
 #pragma unroll
             for (int ct = 0; ct < 4; ct++)
@@ -429,25 +456,41 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
         const int nsum = (hist_end - jf + LA_SLICE - 1) / LA_SLICE;
         const double *P0 = la_part(A, b, (k + 1) & 1, row, 0) + (size_t)w * 1024 + lane;
         int s = 0;
-        for (; s + 1 < nsum; s += 2) {
-            double pa[16], pb[16];
+        // (LA_NSUM slabs per memory round trip, all 64 loads requested before the first addition -- the loop is a chain of round trips
+        //  of 2-4 k cycles each, 12-15 slabs at the end of N = 4096, and the F tasks are the longest of a late step; the order of
+        //  the additions is unchanged)
+        for (; s + LA_NSUM - 1 < nsum; s += LA_NSUM) {
+            double pv[LA_NSUM][16];
 #pragma unroll
-            for (int e = 0; e < 16; e++) pa[e] = P0[(size_t)s * 4096 + e * 64];
+            for (int u = 0; u < LA_NSUM; u++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) pb[e] = P0[(size_t)(s + 1) * 4096 + e * 64];
+                for (int e = 0; e < 16; e++) pv[u][e] = P0[(size_t)(s + u) * 4096 + e * 64];
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] += pa[e];
+            for (int u = 0; u < LA_NSUM; u++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] += pb[e];
+                for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] += pv[u][e];
         }
-        if (s < nsum) {
+        for (; s < nsum; s++) {
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] += P0[(size_t)s * 4096 + e * 64];
         }
+        // F: X_k and the pre-solve copy are requested here, in front of the product of panel k-1 that hides their round trip (held from
+        // the top of the task they would take the registers of two of the four slabs in flight above)
+        if (!is_D && LA_F_LATE) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) xreg[e] = *(const v2d *)(Xg + 2 * (tid + LA_THREADS * e));
+            la_load_t(A.pnx + ((size_t)b * (A.ring + 1) + la_ring(A, k)) * 4096 + (size_t)(16 * w) * 64, 64, pval, li, g);
+        }
+        LA_TF(1);
         // panel k-1 (final since the previous launch); the D role got this term with its head start
         if (!head_start && k >= 1 && jf <= k - 1) la_gemm(Rb, Lb + (size_t)c1 * ld, ld, k - 1, k, acc, sm, tid, w, li, g);
     }
+    if (!has_next && !is_D && LA_F_LATE) {   // last step: only the solve of panel k is left
+#pragma unroll
+        for (int e = 0; e < 8; e++) xreg[e] = *(const v2d *)(Xg + 2 * (tid + LA_THREADS * e));
+    }
     LA_TD(3);
+    LA_TF(2);
     // ---- (2) X_k -> LDS (Bs is dead: la_gemm ends with a barrier)
 #pragma unroll
     for (int e = 0; e < 8; e++) { const int idx = 2 * (tid + LA_THREADS * e); *(v2d *)&sm.Xs[idx >> 6][idx & 63] = xreg[e]; }
@@ -476,7 +519,12 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     if (!has_next) { LA_TEND(1); return 0; }
     __syncthreads();   // Ls complete
     LA_TD(4);
+    LA_TF(3);
     // ---- (5) newest rank-64 term: acc += row_r[C_k] L[C_k+1,C_k]^T, straight from the trsm registers (A operand)
+    if (head_start) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] += dsv[e];
+    }
 #pragma unroll
     for (int ct = 0; ct < 4; ct++)
 #pragma unroll
@@ -492,6 +540,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
         for (int ct = 0; ct < 4; ct++)
 #pragma unroll
             for (int r = 0; r < 4; r++) la_st<PERSIST>(&Rb[(size_t)(16 * w + 4 * r + g) * ld + c1 + 16 * ct + li], -acc[ct][r]);
+        LA_TF(4);
         if (row.kind == 0 && row.blk == k + 2) {   // next step's P_k+2,k+1: everybody reads this copy
             double *Pn = A.pnx + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096;
 #pragma unroll
@@ -523,10 +572,12 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
             // the R workgroup of this launch into A.dsum (left to this workgroup, its chain of up to 15 slab round trips made it
             // the longest task of the launch at N = 4096)
             __syncthreads();   // the rows in Xs have been read: la_gemm stages through the same LDS
+            LA_TF(5);
             if (k >= 1) la_gemm(Rb, Lb + (size_t)c2 * ld, ld, k - 1, k, acc, sm, tid, w, li, g);
             double *Dt = A.dterm + ((size_t)b * (A.ring + 1) + la_ring(A, k + 2)) * 4096 + (size_t)w * 1024 + lane;
 #pragma unroll
             for (int e = 0; e < 16; e++) la_st<PERSIST>(&Dt[e * 64], acc[e >> 2][e & 3]);
+            LA_TF(6);
         }
         LA_TEND(1);
         return 0;
@@ -545,11 +596,14 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     LA_TD(6);
     if (sm.fail) return 1;
     double *Xn = A.xk2 + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096;
-    for (int e = tid; e < 64 * 64; e += LA_THREADS) {
-        const int rr = e >> 6, cc = e & 63;
-        if (cc <= rr) la_st<PERSIST>(&Lb[(size_t)(c1 + rr) * ld + c1 + cc], sm.Xs[rr][cc]);
-        if (want_mode) la_st<PERSIST>(&Ub[(size_t)(c1 + rr) * ld + c1 + cc], (cc >= rr) ? sm.Ls[cc][rr] : 0.0);
-        la_st<PERSIST>(&Xn[e], sm.Ls[rr][cc]);
+    // (two columns per lane and store: 16-byte accesses, 8 passes instead of 16 on the tail of the chain)
+    for (int e = tid; e < 64 * 32; e += LA_THREADS) {
+        const int rr = e >> 5, cc = 2 * (e & 31);
+        const v2d xv = *(const v2d *)&sm.Ls[rr][cc];
+        if (cc + 1 <= rr) la_st2<PERSIST>(&Lb[(size_t)(c1 + rr) * ld + c1 + cc], *(const v2d *)&sm.Xs[rr][cc]);
+        else if (cc == rr) la_st<PERSIST>(&Lb[(size_t)(c1 + rr) * ld + c1 + cc], sm.Xs[rr][cc]);
+        if (want_mode) la_st2<PERSIST>(&Ub[(size_t)(c1 + rr) * ld + c1 + cc], (v2d){(cc >= rr) ? sm.Ls[cc][rr] : 0.0, (cc + 1 >= rr) ? sm.Ls[cc + 1][rr] : 0.0});
+        la_st2<PERSIST>(&Xn[2 * e], xv);
     }
     if (tid == 0) L.scal[b * 4 + 0] += sm.logdet;   // the chain's steps are ordered: fixed summation order
     LA_TEND(0);
@@ -565,13 +619,10 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
 __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A, int k, int want_mode, int nLrowsL, int park) {
     __shared__ LaSmem sm;
     const int b = blockIdx.x;
-    const int st0 = L.status[b], n0 = L.bn[b];      // two independent loads (bslot -> pn would be a dependent chain of three)
-    if (st0 < 0) return;
-    const int n = __builtin_amdgcn_readfirstlane(n0);
-    const int nb = medgp_roundup(n, 64) / 64;
-    if (k >= nb || nb < 2) return;
     if (park >= 0 && (int)blockIdx.y == park) {
-        if (threadIdx.x >= 64 || k + 1 >= nb) return;   // one wave holds the slot; the last step has no chain
+        const int st0 = L.status[b], n0 = L.bn[b];
+        const int nb = medgp_roundup(__builtin_amdgcn_readfirstlane(n0), 64) / 64;
+        if (st0 < 0 || threadIdx.x >= 64 || k + 1 >= nb || nb < 2) return;   // one wave holds the slot; the last step has no chain
         for (int it = 0; it < 2000; it++) {              // <= ~3 ms, far beyond any step
             if (__hip_atomic_load(&A.flag[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > k) break;
             __builtin_amdgcn_s_sleep(64);
@@ -581,8 +632,8 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     const int task = (park >= 0 && (int)blockIdx.y > park) ? (int)blockIdx.y - 1 : (int)blockIdx.y;
     LaTask T;
     if (!la_decode(A, k, want_mode & 1, task, nLrowsL, T)) return;
-    const int failed = la_body<false>(L, A, sm, b, n, k, want_mode, T);
-    if (T.role == 0 && k + 1 < nb && threadIdx.x == 0) {
+    const int failed = la_body<false>(L, A, sm, b, -1, k, want_mode, T);   // (-1: the body reads the entry's status and size itself)
+    if (T.role == 0 && k + 1 < A.nbmax && threadIdx.x == 0) {
         if (failed) L.status[b] = -2;
         __hip_atomic_store(&A.flag[b], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // releases the parked workgroup
     }
