@@ -54,8 +54,7 @@ struct LaArgs {
     int nbmax;            // 64-blocks of the largest patient of the batch
     int maxslice;         // slices per row block the scratch is dimensioned for
     int rows;             // row blocks the scratch is dimensioned for (2 nbmax + 1)
-    int ring;             // index mask of the chain's hand-off slabs xk2 / pnx / dterm / dsum: 1 = by parity (one launch per step);
-                          // 2^m - 1 >= nbmax = one slab per step (persistent schedule: nothing is overwritten inside the launch)
+    int ring;             // index mask of the chain's hand-off slabs xk2 / pnx / dterm / dsum: 1 = by step parity
 };
 
 // row block index inside the scratch: M_i -> i, U_rho -> nbmax + rho, Y -> 2 nbmax
@@ -243,32 +242,13 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
 #define LA_T0() do {} while (0)
 #define LA_TEND(role) do {} while (0)
 #endif
-// One task of step k (the body of k_la_step, shared with the persistent schedule of kernels_cholinv_lp.h).
-// PERSIST = false: one launch per step, every operand was final before the launch, plain stores.
-// PERSIST = true:  the task runs inside ONE launch next to its producers and consumers (other workgroups, other XCDs): every
-//                  byte another workgroup reads later is stored write-through (sc1: la_st), the caller polls the task's
-//                  dependencies, acquires, and publishes the task's completion afterwards; the ring indices of the chain's
-//                  hand-off slabs (xk2, pnx, dterm, dsum) are the step itself instead of its parity (LaArgs::ring).
+// One task of step k: the body of k_la_step.
 struct LaTask {
     int role;             // 0 = D (diagonal chain), 1 = F, 2 = L (look-ahead), 3 = R
     LaRow row;
     int slice;
     bool diag_ahead;
 };
-template <bool PERSIST> __device__ __forceinline__ void la_st(double *p, double v) {
-    if constexpr (PERSIST) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store_dwordx2 sc1
-    else *p = v;
-}
-template <bool PERSIST> __device__ __forceinline__ void la_st2(double *p, v2d v) {   // 16-byte aligned pair
-    if constexpr (PERSIST) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-    else *(v2d *)p = v;
-}
-template <bool PERSIST> __device__ __forceinline__ void la_store_tp(double *blk, int ld, const v4d (&o)[4], int li, int g) {
-#pragma unroll
-    for (int ct = 0; ct < 4; ct++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) la_st<PERSIST>(&blk[(size_t)li * ld + 16 * ct + 4 * r + g], o[ct][r]);
-}
 // slab index of a chain hand-off buffer for step / block x
 __device__ __forceinline__ int la_ring(const LaArgs &A, int x) { return x & A.ring; }
 
@@ -315,8 +295,7 @@ __device__ __forceinline__ bool la_decode(const LaArgs &A, int k, int want_inv, 
     return true;
 }
 
-// returns 1 when the D role met a non-positive pivot (status -2 is set by the caller's protocol), else 0
-template <bool PERSIST>
+// returns 1 when the D role met a non-positive pivot (the caller marks the entry: status -2), else 0
 __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSmem &sm, int b, int n_in, int k, int want_mode, const LaTask &T) {
     LA_T0();
     const int ld = L.ldn;
@@ -386,7 +365,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
         }
         double *Ds = A.dsum + ((size_t)b * (A.ring + 1) + la_ring(A, k + 2)) * 4096 + (size_t)w * 1024 + lane;
 #pragma unroll
-        for (int e = 0; e < 16; e++) la_st<PERSIST>(&Ds[e * 64], sacc[e]);
+        for (int e = 0; e < 16; e++) Ds[e * 64] = sacc[e];
         return 0;
     }
 
@@ -407,7 +386,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
 #pragma unroll
         for (int ct = 0; ct < 4; ct++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) la_st<PERSIST>(&P[(ct * 4 + r) * 64], acc[ct][r]);
+            for (int r = 0; r < 4; r++) P[(ct * 4 + r) * 64] = acc[ct][r];
         LA_TEND(2);
         return 0;
     }
@@ -503,7 +482,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
         for (int ct = 0; ct < 4; ct++)
 #pragma unroll
             for (int r = 0; r < 4; r++) sm.Ls[16 * w + li][16 * ct + 4 * r + g] = o[ct][r];
-        if (is_D) la_store_tp<PERSIST>(Lb + (size_t)(c1 + 16 * w) * ld + c0, ld, o, li, g);   // final L[C_k+1, C_k]
+        if (is_D) la_store_t(Lb + (size_t)(c1 + 16 * w) * ld + c0, ld, o, li, g);   // final L[C_k+1, C_k]
     }
     // ---- (4) own rows of panel k: row_r[C_k] = P_r,k X_k^T   (D: that is the block above, already in o;  U_k: the
     //      diagonal block U_kk itself, final since the previous launch)
@@ -513,7 +492,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
             v4d oval[4];
             la_load_t(oblk, ld, oval, li, g);
             la_trsm(sm.Xs, oval, o, li, g);
-            la_store_tp<PERSIST>(oblk, ld, o, li, g);
+            la_store_t(oblk, ld, o, li, g);
         }
     }
     if (!has_next) { LA_TEND(1); return 0; }
@@ -539,14 +518,14 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
 #pragma unroll
         for (int ct = 0; ct < 4; ct++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) la_st<PERSIST>(&Rb[(size_t)(16 * w + 4 * r + g) * ld + c1 + 16 * ct + li], -acc[ct][r]);
+            for (int r = 0; r < 4; r++) Rb[(size_t)(16 * w + 4 * r + g) * ld + c1 + 16 * ct + li] = -acc[ct][r];
         LA_TF(4);
         if (row.kind == 0 && row.blk == k + 2) {   // next step's P_k+2,k+1: everybody reads this copy
             double *Pn = A.pnx + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096;
 #pragma unroll
             for (int ct = 0; ct < 4; ct++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) la_st<PERSIST>(&Pn[(16 * w + 4 * r + g) * 64 + 16 * ct + li], -acc[ct][r]);
+                for (int r = 0; r < 4; r++) Pn[(16 * w + 4 * r + g) * 64 + 16 * ct + li] = -acc[ct][r];
             // diagonal head start for the NEXT launch's chain (row block k+2 is its D role):  -K[k+2, k+2] + row[C_k] row[C_k]^T,
             // this workgroup's 64 rows of panel k (o, final) times themselves.  X_k in Xs is dead (every wave passed the barrier
             // after its trsm), so the rows go there as the shared operand; acc is free again.
@@ -576,7 +555,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
             if (k >= 1) la_gemm(Rb, Lb + (size_t)c2 * ld, ld, k - 1, k, acc, sm, tid, w, li, g);
             double *Dt = A.dterm + ((size_t)b * (A.ring + 1) + la_ring(A, k + 2)) * 4096 + (size_t)w * 1024 + lane;
 #pragma unroll
-            for (int e = 0; e < 16; e++) la_st<PERSIST>(&Dt[e * 64], acc[e >> 2][e & 3]);
+            for (int e = 0; e < 16; e++) Dt[e * 64] = acc[e >> 2][e & 3];
             LA_TF(6);
         }
         LA_TEND(1);
@@ -600,10 +579,10 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     for (int e = tid; e < 64 * 32; e += LA_THREADS) {
         const int rr = e >> 5, cc = 2 * (e & 31);
         const v2d xv = *(const v2d *)&sm.Ls[rr][cc];
-        if (cc + 1 <= rr) la_st2<PERSIST>(&Lb[(size_t)(c1 + rr) * ld + c1 + cc], *(const v2d *)&sm.Xs[rr][cc]);
-        else if (cc == rr) la_st<PERSIST>(&Lb[(size_t)(c1 + rr) * ld + c1 + cc], sm.Xs[rr][cc]);
-        if (want_mode) la_st2<PERSIST>(&Ub[(size_t)(c1 + rr) * ld + c1 + cc], (v2d){(cc >= rr) ? sm.Ls[cc][rr] : 0.0, (cc + 1 >= rr) ? sm.Ls[cc + 1][rr] : 0.0});
-        la_st2<PERSIST>(&Xn[2 * e], xv);
+        if (cc + 1 <= rr) *(v2d *)&Lb[(size_t)(c1 + rr) * ld + c1 + cc] = *(const v2d *)&sm.Xs[rr][cc];
+        else if (cc == rr) Lb[(size_t)(c1 + rr) * ld + c1 + cc] = sm.Xs[rr][cc];
+        if (want_mode) *(v2d *)&Ub[(size_t)(c1 + rr) * ld + c1 + cc] = (v2d){(cc >= rr) ? sm.Ls[cc][rr] : 0.0, (cc + 1 >= rr) ? sm.Ls[cc + 1][rr] : 0.0};
+        *(v2d *)&Xn[2 * e] = xv;
     }
     if (tid == 0) L.scal[b * 4 + 0] += sm.logdet;   // the chain's steps are ordered: fixed summation order
     LA_TEND(0);
@@ -632,7 +611,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
     const int task = (park >= 0 && (int)blockIdx.y > park) ? (int)blockIdx.y - 1 : (int)blockIdx.y;
     LaTask T;
     if (!la_decode(A, k, want_mode & 1, task, nLrowsL, T)) return;
-    const int failed = la_body<false>(L, A, sm, b, -1, k, want_mode, T);   // (-1: the body reads the entry's status and size itself)
+    const int failed = la_body(L, A, sm, b, -1, k, want_mode, T);   // (-1: the body reads the entry's status and size itself)
     if (T.role == 0 && k + 1 < A.nbmax && threadIdx.x == 0) {
         if (failed) L.status[b] = -2;
         __hip_atomic_store(&A.flag[b], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // releases the parked workgroup

@@ -7,7 +7,7 @@
 #include "kernels_v0.h"
 #include "kernels_cholinv.h"
 #include "kernels_cholinv_mc.h"
-#include "kernels_cholinv_lp.h"
+#include "kernels_cholinv_la.h"
 #include "kernels_assemble.h"
 #include "kernels_wgrad.h"
 #include "kernels_io.h"
@@ -94,10 +94,6 @@ struct medgp_ctx {
     bool use_v0 = false;      // MEDGP_V0=1: baseline kernels (debug / A-B parity)
     int cholinv_nw = 0;       // MEDGP_CHOLINV_NW=44|84 forces the workgroup shape <waves, 16-row units per wave> (0 = auto)
     int la_park = 256;        // MEDGP_LA_PARK=<workgroup id>|0: where the look-ahead schedule parks its sleeping workgroup (0 = off)
-    int la_persist = 0;       // MEDGP_LA_PERSIST=0|1 (default 0: measured slower): the look-ahead schedule as one persistent launch (kernels_cholinv_lp.h) for batches of at
-    int la_persist_maxbatch = 8;   //                       most MEDGP_LA_PERSIST_MAXBATCH entries; 0 = one launch per step for every batch
-    unsigned *d_lp_sync = nullptr; // ticket head + completion counters of the persistent schedule (zeroed before every launch)
-    size_t lp_sync_cap = 0;
     int la_park_maxbatch = 8; // MEDGP_LA_PARK_MAXBATCH: largest batch the parking is used for (measured: 4 x N=2048 -5 %, 16 x N=2048 +2 %)
     int force_mc = 0;         // MEDGP_MULTI_CU=1 forces / -1 forbids the multi-CU factorisation (0 = auto)
     int num_cu = 256;
@@ -266,13 +262,12 @@ int d2h_pinned(medgp_ctx *c, const void *dev, size_t bytes, const char **out) {
 }
 
 // scratch of the look-ahead factorisation for `nbatch` entries of at most `nbmax` 64-blocks (freed by free_all)
-int ensure_la(medgp_ctx *c, int nbatch, int nbmax, bool persist, LaArgs *out) {
+int ensure_la(medgp_ctx *c, int nbatch, int nbmax, LaArgs *out) {
     LaArgs A{};
     A.nbmax = nbmax;
     A.maxslice = (nbmax + LA_SLICE - 1) / LA_SLICE;
     A.rows = 2 * nbmax + 1;
     A.ring = 1;
-    if (persist) { int r = 2; while (r < nbmax + 1) r *= 2; A.ring = r - 1; }   // one hand-off slab per step
     const size_t nring = (size_t)A.ring + 1;
     const size_t need_part = (size_t)nbatch * 2 * A.rows * A.maxslice * 4096;
     const size_t need_small = (size_t)nbatch * (64 * (size_t)c->ldn + 4 * nring * 4096 + 2 * (size_t)A.maxslice * 4096 + 1);
@@ -382,8 +377,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
 #endif
         {
             LaArgs la{};
-            const bool persist = c->la_persist && nbatch <= c->la_persist_maxbatch && nt64 >= 2;
-            { int rc = ensure_la(c, nbatch, nt64, persist, &la); if (rc) return rc; }
+            { int rc = ensure_la(c, nbatch, nt64, &la); if (rc) return rc; }
             launch_assemble();
             // entries of a single 64-block: one workgroup each (the same kernel, hence the same bits, as in any other call)
             if (any_small) { Launcher l(c, KID_CHOLINV, stream); hipLaunchKernelGGL((k_cholinv<8, 4, 1>), dim3(nbatch), dim3(512), 0, stream, L, want_mode); }
@@ -394,32 +388,6 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
                 *nLrows = (k + 2 < nt64 && k >= 1) ? nMF + nUL + 1 : 0;
                 *nsl = std::min(la.maxslice, (k + LA_SLICE - 1) / LA_SLICE);   // history slices that exist at step k
             };
-            if (persist) {
-                // look-ahead schedule as ONE launch: a chain workgroup per entry + workgroups that pull the F / R / L tasks of all
-                // steps from a ticket counter (kernels_cholinv_lp.h)
-                LpArgs lp{};
-                const size_t words = ((size_t)LP_HDR + (size_t)nbatch * (4 + 4 * (size_t)nt64) + 3) / 4 * 4;
-                if (words > c->lp_sync_cap) {
-                    HIPCHK(c, hipDeviceSynchronize());
-                    if (c->d_lp_sync) { (void)hipFree(c->d_lp_sync); c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), (void *)c->d_lp_sync), c->allocs.end()); c->d_lp_sync = nullptr; c->lp_sync_cap = 0; }
-                    void *pp = nullptr;
-                    HIPCHK(c, hipMalloc(&pp, words * sizeof(unsigned)));
-                    c->allocs.push_back(pp);
-                    c->d_lp_sync = (unsigned *)pp;
-                    c->lp_sync_cap = words;
-                }
-                HIPCHK(c, hipMemsetAsync(c->d_lp_sync, 0, words * sizeof(unsigned), stream));
-                long total = 0;
-                for (int k = 0; k < nt64; k++) { int nF, nLrows, nsl; step_counts(k, &nF, &nLrows, &nsl); total += (long)(nF + 1 + nLrows * nsl) * nbatch; }
-                lp.sync = c->d_lp_sync;
-                lp.nbatch = nbatch;
-                lp.total = (int)total;
-                const long want = (long)nbatch + total, cap = 2L * c->num_cu;   // two workgroups per CU are resident (LDS)
-                int grid = (int)std::min(want, cap);
-                lp.park = (c->la_park > 0 && nbatch <= c->la_park_maxbatch && grid > c->la_park + nbatch) ? c->la_park : -1;
-                Launcher l(c, KID_LA_STEP, stream);
-                hipLaunchKernelGGL(k_lp_run, dim3(grid), dim3(LA_THREADS), 0, stream, L, la, lp, want_mode);
-            } else
             // look-ahead schedule: one launch per 64-wide step (kernels_cholinv_la.h)
             for (int k = 0; k < nt64; k++) {
                 int nF, nLrows, nsl;
@@ -584,8 +552,6 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     { const char *e = getenv("MEDGP_CHOLINV_NW"); c->cholinv_nw = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_LA_PARK"); if (e) c->la_park = atoi(e); }
     { const char *e = getenv("MEDGP_LA_PARK_MAXBATCH"); if (e) c->la_park_maxbatch = atoi(e); }
-    { const char *e = getenv("MEDGP_LA_PERSIST"); if (e) c->la_persist = atoi(e); }
-    { const char *e = getenv("MEDGP_LA_PERSIST_MAXBATCH"); if (e) c->la_persist_maxbatch = atoi(e); }
     { const char *e = getenv("MEDGP_MULTI_CU"); c->force_mc = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_STREAMS"); c->nsplit = e ? atoi(e) : 1; }
     { const char *e = getenv("MEDGP_DEBUG_FAIL_ATTEMPTS"); c->dbg_fail = e ? atoi(e) : 0; }
@@ -1319,9 +1285,9 @@ int medgp_kde_mode_at(int device, int nseries, const int64_t *off, const int32_t
             for (int i = 0; i < tcnt[s]; i++)
                 if (!std::isfinite(test[toff[s] + i])) { status[s] = -1; mode[s] = std::nan(""); break; }
     }
-    if (e0) hipEventDestroy(e0);
-    if (e1) hipEventDestroy(e1);
-    hipFree(d_off); hipFree(d_cnt); hipFree(d_st); hipFree(d_x); hipFree(d_mode); hipFree(d_bw); hipFree(d_stats); hipFree(d_part); hipFree(d_toff); hipFree(d_tcnt); hipFree(d_test);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    for (void *q : {(void *)d_off, (void *)d_cnt, (void *)d_st, (void *)d_x, (void *)d_mode, (void *)d_bw, (void *)d_stats, (void *)d_part, (void *)d_toff, (void *)d_tcnt, (void *)d_test}) (void)hipFree(q);
     return rc;
 }
 
