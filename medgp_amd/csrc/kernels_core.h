@@ -11,10 +11,11 @@
 // The tables implement cos(w (t_i - t_j)) = cs_i cs_j + sn_i sn_j, so the N^2 pair loop needs no
 // trigonometric evaluation (c_kernel_LMC_SM.cpp:374-378 evaluates cos per pair).
 // ------------------------------------------------------------------------------------------
-// grid = (nbatch, 1 + table chunks): block y = 0 transforms the hypers (and resets the per-entry state), blocks y >= 1 fill
-// PREP_CHUNK entries of the cos / sin tables each (they derive w_q from theta themselves, so no block waits for another;
+// grid = (nbatch, 1 + table chunks + B chunks): block y = 0 transforms the hypers (and resets the per-entry state), the next blocks fill
+// PREP_CHUNK entries of the cos / sin tables each, the last ones PREP_BCHUNK entries of the B_q each (they derive w_q from theta themselves, so no block waits for another;
 // one workgroup per entry made a single N = 4096, Q = 5 evaluation spend 0.12 ms here).
 #define PREP_CHUNK 2048
+#define PREP_BCHUNK 256   // LMC-SM: entries of the coregionalisation matrices B_q per workgroup of the blocks behind the table chunks
 __device__ __forceinline__ double prep_w(const MedgpDev &L, const double *th, int q) {
     if (L.kidx == 7) return 2.0 * L.pi * exp(th[L.D + L.Q * L.D * L.R + q]);
     if (L.kidx == 8) return 2.0 * L.pi * exp(th[1 + L.Q + q]);
@@ -29,6 +30,22 @@ __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restri
     double *sig2 = hyp, *B = hyp + hyp_off_B(L), *w = hyp + hyp_off_w(L), *c = hyp + hyp_off_c(L);
     const int Q = L.Q, D = L.D, R = L.R;
     const double pi = L.pi;
+    const int ntab = (Q * L.ldn + PREP_CHUNK - 1) / PREP_CHUNK;
+    if ((int)blockIdx.y > ntab) {
+        // ---- B_q = A_q A_q^T + diag(kappa_q), one entry per thread (left to the block of y = 0, its 256 threads walked Q D^2 / 256
+        //      entries of R dependent load pairs each: 80 of the 89 us this kernel took for one D = 64 evaluation)
+        if (theta == nullptr || L.kidx != 7) return;
+        const int idx = ((int)blockIdx.y - ntab - 1) * PREP_BCHUNK + tid;
+        if (idx >= Q * D * D) return;
+        const double *A = th + D, *lk = th + D + Q * (D * R + 2);
+        const int q = idx / (D * D), rem = idx - q * D * D, i = rem / D, j = rem - i * D;
+        const double *Ai = A + ((size_t)q * D + i) * R, *Aj = A + ((size_t)q * D + j) * R;
+        double s = 0.0;
+        for (int r = 0; r < R; r++) s += Ai[r] * Aj[r];
+        if (i == j) s += exp(lk[q * D + i]);
+        B[idx] = s;
+        return;
+    }
     if (blockIdx.y >= 1) {
         // ---- cos / sin tables.  theta == nullptr (tables only, medgp_get_factor's caller-order re-factorisation): the
         //      hyper block of this entry is kept, w_q is read from it
@@ -59,15 +76,6 @@ __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restri
     if (theta == nullptr) return;
     if (L.kidx == 7) {
         for (int d = tid; d < D; d += nt) { double s = exp(th[d]); sig2[d] = s * s; }
-        const double *A = th + D, *lk = th + D + Q * (D * R + 2);
-        for (int idx = tid; idx < Q * D * D; idx += nt) {
-            int q = idx / (D * D), rem = idx - q * D * D, i = rem / D, j = rem - i * D;
-            const double *Ai = A + ((size_t)q * D + i) * R, *Aj = A + ((size_t)q * D + j) * R;
-            double s = 0.0;
-            for (int r = 0; r < R; r++) s += Ai[r] * Aj[r];
-            if (i == j) s += exp(lk[q * D + i]);
-            B[idx] = s;
-        }
         for (int q = tid; q < Q; q += nt) {
             double v = exp(th[D + Q * D * R + Q + q]);
             double pv = pi * v;

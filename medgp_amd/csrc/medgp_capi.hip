@@ -304,7 +304,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
                      int flag_grad, bool need_inverse, int min_n, double *nlml_dev, double *grad_dev, int32_t *status_dev,
                      bool store_ukk, const int *entry_n) {
     const int nt64 = medgp_roundup(std::max(max_n, 1), 64) / 64;
-    { Launcher l(c, KID_PREP, stream); hipLaunchKernelGGL(k_prep, dim3(nbatch, 1 + (L.Q * L.ldn + PREP_CHUNK - 1) / PREP_CHUNK), dim3(256), 0, stream, L, theta_dev, min_n); }
+    { Launcher l(c, KID_PREP, stream); hipLaunchKernelGGL(k_prep, dim3(nbatch, 1 + (L.Q * L.ldn + PREP_CHUNK - 1) / PREP_CHUNK + ((theta_dev && L.kidx == 7) ? (L.Q * L.D * L.D + PREP_BCHUNK - 1) / PREP_BCHUNK : 0)), dim3(256), 0, stream, L, theta_dev, min_n); }
     auto launch_assemble = [&]() {
         Launcher l(c, KID_ASSEMBLE, stream);
         const dim3 tg(tri(nt64), nbatch), tb(256);
