@@ -276,6 +276,21 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
         }
         __syncthreads();
     }
+    // the D noise gradients are sums of diag(W) over the observations of one output: one wave each (lanes stride over the segment,
+    // fixed butterfly) -- a single thread per output walked N / D dependent loads (85 at N = 2048, D = 24: 40 of the 46 us this
+    // kernel took for one such evaluation)
+    __shared__ double s_sig[MEDGP_MAX_D];
+    const bool par_sig = flag_grad && L.kidx == 7 && h0 < D;
+    if (par_sig) {
+        const int lane = tid & 63, nwave = nt >> 6, dhi = min(D, h1);
+        for (int d = h0 + (tid >> 6); d < dhi; d += nwave) {
+            double sacc = 0.0;
+            for (int i = seg[d] + lane; i < seg[d + 1]; i += 64) sacc += Wd[(size_t)i * wds];
+            for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off);
+            if (lane == 0) s_sig[d] = sacc;
+        }
+        __syncthreads();
+    }
     // a caller-order copy of a patient (slot + max_slots, nlml-only evaluations) shares the prior of its patient
     const int pslot = slot >= L.max_slots ? slot - L.max_slots : slot;
     const MedgpPrior *pr = L.prior_on[pslot] ? L.prior + (size_t)pslot * H : nullptr;
@@ -288,11 +303,7 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
         if (L.kidx == 7) {
             if (h < D) {
                 hv = exp(th[h]);
-                if (flag_grad) {
-                    double s = 0.0;
-                    for (int i = seg[h]; i < seg[h + 1]; i++) s += hv * hv * Wd[(size_t)i * wds];
-                    gv = s;   // ref: c_inference_exact.cpp:194-202
-                }
+                if (flag_grad) gv = (hv * hv) * s_sig[h];   // ref: c_inference_exact.cpp:194-202
             } else {
                 int hc = h - D;
                 if (hc < Q * D * R) {
