@@ -266,10 +266,14 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
             const int q = (w2 < Q) ? w2 : w2 - Q;
             const double *X = ((w2 < Q) ? SM : SV) + (size_t)q * D * D, *Bq = B + (size_t)q * D * D;
             double sacc = 0.0;
+            // (the bin index is decoded once and then advanced: tile_decode -- a double square root and two correction loops --
+            //  per term was 26 of the 62 us this kernel took at D = 64; same terms in the same order)
+            int d, e;
+            tile_decode(lane, d, e);
             for (int idx = lane; idx < nbins; idx += 64) {
-                int d, e;
-                tile_decode(idx, d, e);
                 sacc += ((d == e) ? 1.0 : 2.0) * Bq[d * D + e] * X[d * D + e];
+                e += 64;
+                while (e > d) { e -= d + 1; d++; }
             }
             for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off);
             if (lane == 0) smuv[w2] = sacc;
@@ -315,9 +319,24 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
                             const double *A = s_A + q * D * R, *Sq = s_S + q * D * D;
                             for (int e = 0; e < D; e++) s += sym_get(Sq, D, d, e) * A[e * R + r];
                         } else {
+                            // (S_q does not fit the LDS copy, D > 28 at Q = 5: one load per term through a selected INDEX and eight
+                            //  terms in flight -- with a branch per term the 2 D loads of a dot product came back one at a time:
+                            //  45 of the 62 us of this kernel at D = 64)
                             const double *A = th + D + (size_t)q * D * R;
                             const double *Sq = S + (size_t)q * D * D;
-                            for (int e = 0; e < D; e++) s += sym_get(Sq, D, d, e) * A[e * R + r];
+                            int e = 0;
+                            for (; e + 8 <= D; e += 8) {
+                                double sv[8], av[8];
+#pragma unroll
+                                for (int u = 0; u < 8; u++) {
+                                    const int ee = e + u, ix = (d >= ee) ? d * D + ee : ee * D + d;
+                                    sv[u] = Sq[ix];
+                                    av[u] = A[ee * R + r];
+                                }
+#pragma unroll
+                                for (int u = 0; u < 8; u++) s += sv[u] * av[u];
+                            }
+                            for (; e < D; e++) s += sym_get(Sq, D, d, e) * A[e * R + r];
                         }
                         gv = s;
                     }
