@@ -322,9 +322,11 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     }
     int n = n_in;
     if (n_in < 0) {
-        const int st0 = L.status[b], n0 = L.bn[b];      // two independent loads (bslot -> pn would be a dependent chain of three)
-        if (st0 < 0) return 0;
-        n = __builtin_amdgcn_readfirstlane(n0);
+        // the two words are requested together and merged arithmetically: with `if (st0 < 0) return` in between, the compiler
+        // issues the size word only behind the branch -- a second scalar-memory round trip at the head of every task.  A failed
+        // entry (status < 0) gets n = 0, which the size check below turns into the same early return.
+        const int st0 = L.status[b], n0 = L.bn[b];
+        n = __builtin_amdgcn_readfirstlane(n0 & ~(st0 >> 31));
     }
     const int npad = medgp_roundup(n, 64), nb = npad / 64;
     if (k >= nb || nb < 2) return 0;
