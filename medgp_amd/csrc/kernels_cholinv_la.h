@@ -173,9 +173,11 @@ __device__ __forceinline__ void la_store_t(double *blk, int ld, const v4d (&o)[4
 __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A, int want_mode) {
     __shared__ LaSmem sm;
     const int b = blockIdx.x;
-    if (L.status[b] < 0) return;
-    const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
-    if (nb < 2) return;   // single-block entries are factored by k_cholinv (see its only_small switch)
+    // status, size (k_prep's copy) and slot are requested together: `status -> branch -> slot -> size of the slot` was a chain of three
+    // scalar-memory round trips in front of the first factorisation
+    const int st0 = L.status[b], n0 = L.bn[b], slot = L.bslot[b];
+    const int n = __builtin_amdgcn_readfirstlane(n0 & ~(st0 >> 31)), ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
+    if (nb < 2) return;   // failed entries (n = 0) and single-block entries: the latter are factored by k_cholinv (see its only_small switch)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (blockIdx.y == 0 && tid == 0) A.flag[b] = 0;
@@ -626,8 +628,9 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
 __global__ void __launch_bounds__(256) k_la_finish(MedgpDev L, LaArgs A, int want_mode) {
     __shared__ double red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (L.status[b] < 0) return;
-    const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
+    const int st0 = L.status[b], n0 = L.bn[b];
+    if (st0 < 0) return;
+    const int n = n0, ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;
     const int rq = blockIdx.y;
     if (16 * rq >= npad || nb < 2) return;
     const double *zrow = A.ybuf + (size_t)b * 64 * ld;   // row 0 of the Y block
