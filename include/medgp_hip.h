@@ -203,7 +203,9 @@ int medgp_kde_mode_at(int device, int nseries, const int64_t *off, const int32_t
 int medgp_synchronize(medgp_ctx *ctx);
 
 /* ---- measurement hooks (bench.py roofline leg; no effect on results) ------------------------- */
-/* enable = 1: bracket every kernel launch with HIP events on the launch stream */
+/* enable = 1: bracket every kernel launch with HIP events on the launch stream; enable = 2 + k: only the launches of kernel k
+   (medgp_profile_kernel_name) -- two events per step instead of two per launch (bench.py times its headline region this way:
+   the events of all seven launches cost 1.6 % of a 512-patient step); enable = 0: off */
 int medgp_profile_enable(medgp_ctx *ctx, int enable);
 /* number of distinct kernels the library launches, and their names */
 int medgp_profile_num_kernels(void);

@@ -312,8 +312,13 @@ class Context:
         self._chk(self._lib.medgp_synchronize(self._h))
 
     # measurement hooks
-    def profile_enable(self, on=True):
-        self._chk(self._lib.medgp_profile_enable(self._h, int(bool(on))))
+    def profile_enable(self, on=True, only=None):
+        """on: bracket every launch with HIP events; only='k_cholinv': just the launches of that kernel."""
+        mode = int(bool(on))
+        if on and only is not None:
+            names = [self._lib.medgp_profile_kernel_name(k).decode() for k in range(self._lib.medgp_profile_num_kernels())]
+            mode = 2 + names.index(only)
+        self._chk(self._lib.medgp_profile_enable(self._h, mode))
 
     def profile_reset(self):
         self._chk(self._lib.medgp_profile_reset(self._h))

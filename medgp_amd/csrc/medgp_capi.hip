@@ -91,6 +91,7 @@ struct medgp_ctx {
     int pred_cap = 0;
     // profiling
     bool profiling = false;
+    int profile_only = -1;    // >= 0: only launches of this kernel id are bracketed (medgp_profile_enable(ctx, 2 + id))
     bool use_v0 = false;      // MEDGP_V0=1: baseline kernels (debug / A-B parity)
     int cholinv_nw = 0;       // MEDGP_CHOLINV_NW=44|84 forces the workgroup shape <waves, 16-row units per wave> (0 = auto)
     int la_park = 256;        // MEDGP_LA_PARK=<workgroup id>|0: where the look-ahead schedule parks its sleeping workgroup (0 = off)
@@ -155,8 +156,10 @@ struct Launcher {
     int kid;
     hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
+    bool on;
     Launcher(medgp_ctx *c_, int kid_, hipStream_t st_ = nullptr) : c(c_), kid(kid_), st(st_ ? st_ : c_->stream) {
-        if (c->profiling) {
+        on = c->profiling && (c->profile_only < 0 || c->profile_only == kid);
+        if (on) {
             a = take(); b = take();
             (void)hipEventRecord(a, st);
         }
@@ -168,7 +171,7 @@ struct Launcher {
         return e;
     }
     ~Launcher() {
-        if (c->profiling) {
+        if (on) {
             (void)hipEventRecord(b, st);
             if (kid >= 0) c->events.push_back({kid, a, b});
             else { c->ev_pool.push_back(a); c->ev_pool.push_back(b); }   // recorded but never read: safe to re-record later
@@ -1190,6 +1193,7 @@ int medgp_profile_enable(medgp_ctx *c, int enable) {
         while (c->ev_pool.size() < 512) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreate(&e)); c->ev_pool.push_back(e); }
     }
     c->profiling = enable != 0;
+    c->profile_only = (enable >= 2 && enable - 2 < KID_COUNT) ? enable - 2 : -1;
     return MEDGP_OK;
 }
 int medgp_profile_num_kernels(void) { return KID_COUNT; }
