@@ -182,3 +182,27 @@ def test_pinned_ring_wraps_without_corrupting_queued_uploads():
     for k, nl in outs:
         assert np.array_equal(nl.cpu().numpy(), ref[k])
     ctx.close()
+
+
+def test_profile_only_one_kernel_brackets_just_that_kernel():
+    """medgp_profile_enable(ctx, 2 + k) (bench.py's timed region): events around the launches of ONE kernel; results untouched."""
+    P, D, N, Q, R = 6, 3, 130, 2, 2
+    pts, th = synth.cohort(5, P, D, N, Q=Q, R=R)
+    ctx = medgp_amd.Context(7, Q, D, R)
+    ctx.reserve(P, N, P)
+    ctx.set_patients(np.arange(P), pts)
+    ref = ctx.nlml_grad(np.arange(P), th, True)
+    ctx.profile_reset()
+    ctx.profile_enable(True, only="k_wgrad")
+    for _ in range(3):
+        got = ctx.nlml_grad(np.arange(P), th, True)
+    prof = {k: v for k, v in ctx.profile_read().items() if v[1] > 0}
+    ctx.profile_enable(False)
+    assert list(prof) == ["k_wgrad"] and prof["k_wgrad"][1] == 3 and prof["k_wgrad"][0] > 0.0
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    ctx.nlml_grad(np.arange(P), th, True)
+    full = {k for k, v in ctx.profile_read().items() if v[1] > 0}
+    ctx.profile_enable(False)
+    assert {"k_prep", "k_assemble", "k_wgrad", "k_epilogue"} <= full
