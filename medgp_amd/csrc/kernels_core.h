@@ -215,7 +215,7 @@ __device__ inline double sym_get(const double *S, int D, int d, int e) { return 
 __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__restrict__ theta, int flag_grad, int from_slab,
                                                   double *__restrict__ nlml_out, double *__restrict__ grad_out,
                                                   int *__restrict__ status_out) {
-    __shared__ double red[256];
+    __shared__ double red2[MEDGP_EPI_PARTS][256];   // per-chunk partial sums of the prior log-density
     // LDS copies of S_q (all q) and of A for the Q D R gradients dA_q = S_q A_q (each a D-term dot product whose
     // operands otherwise come from global memory one dependent pair at a time); used when they fit
     constexpr int EPI_S_MAX = 4096, EPI_A_MAX = 1280;
@@ -389,19 +389,24 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
         if (pr) prior_apply(pr[h], hv, L.pi, flag_grad != 0, lp_local, gv);
         if (flag_grad && g) g[h] = gv;
     }
-    // deterministic reduction of the chunk's prior log-density
-    __syncthreads();
-    red[tid] = lp_local;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) red[tid] += red[tid + off];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        if (nparts > 1) __hip_atomic_store(&L.epi_lp[(size_t)b * MEDGP_EPI_PARTS + ch], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        lp_part += red[0];
-    }
+    red2[ch - ch0][tid] = lp_local;   // (own slot: no barrier between the chunks)
   }
+    // deterministic reduction of every chunk's prior log-density: ONE tree for all chunks of the part (a tree per chunk put
+    // 10 barriers between two chunks, 40 of them at the headline shape's five chunks; same tree per chunk -> same bits)
+    {
+        const int nc = ch1 - ch0;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off)
+                for (int c2 = 0; c2 < nc; c2++) red2[c2][tid] += red2[c2][tid + off];
+            __syncthreads();
+        }
+        if (tid == 0)
+            for (int c2 = 0; c2 < nc; c2++) {
+                if (nparts > 1) __hip_atomic_store(&L.epi_lp[(size_t)b * MEDGP_EPI_PARTS + ch0 + c2], red2[c2][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lp_part += red2[c2][0];
+            }
+    }
     if (tid == 0) {
         double lp = lp_part;
         if (nparts > 1) {
