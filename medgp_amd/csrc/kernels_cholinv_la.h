@@ -486,7 +486,8 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
         for (int ct = 0; ct < 4; ct++)
 #pragma unroll
             for (int r = 0; r < 4; r++) sm.Ls[16 * w + li][16 * ct + 4 * r + g] = o[ct][r];
-        if (is_D) la_store_t(Lb + (size_t)(c1 + 16 * w) * ld + c0, ld, o, li, g);   // final L[C_k+1, C_k]
+        // (D: the final L[C_k+1, C_k] goes to memory from this LDS tile, row-contiguous, in front of the factorisation -- from the
+        //  registers it took 16 store instructions of 16 rows x 32 bytes each: 3.1 k cycles of issue on the chain)
     }
     // ---- (4) own rows of panel k: row_r[C_k] = P_r,k X_k^T   (D: that is the block above, already in o;  U_k: the
     //      diagonal block U_kk itself, final since the previous launch)
@@ -568,6 +569,10 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     LA_TD(5);
     // ---- (6) D: factor the next diagonal block
     __syncthreads();   // every wave is done reading Xs / Ls
+    for (int e = tid; e < 64 * 32; e += LA_THREADS) {   // final L[C_k+1, C_k]: 16-byte accesses, whole lines
+        const int rr = e >> 5, cc = 2 * (e & 31);
+        *(v2d *)&Lb[(size_t)(c1 + rr) * ld + c0 + cc] = *(const v2d *)&sm.Ls[rr][cc];
+    }
     if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
 #pragma unroll
     for (int ct = 0; ct < 4; ct++)
