@@ -27,7 +27,14 @@
 
 #define LA_KC 32          // history columns staged per barrier
 #define LA_THREADS 256
-#define LA_SLICE 4        // panels (64 columns each) per look-ahead slice
+#define LA_SLICE 4        // panels (64 columns each) per look-ahead slice: the shortest slice (scratch is dimensioned for it)
+// Panels per slice of the partial sums PRODUCED at step k (consumed one step later).  It depends on the step alone -- not on the batch
+// or on the batch-mates' sizes, so a patient's arithmetic is the same in any call.  Late steps of a long factorisation use longer
+// slices: a single N = 4096 evaluation has 526-600 tasks per step from k = 37 on, a few more than the chip's 512 workgroup slots,
+// and paid a second, nearly empty round of 24-us tasks per step.  Measured at N = 4096 (k_la_step, interleaved on one box): 4 panels
+// throughout 2.20 ms; 5 from step 36 2.17; 5 from 36 + 6 from 52 2.11; 5 from 32 + 6 from 44 (this rule) 2.08; longer slices or
+// earlier switches 2.09-2.12.  (N <= 2048 never reaches step 32: unchanged.)
+__host__ __device__ inline int la_slice_len(int k) { return k < 32 ? LA_SLICE : (k < 44 ? LA_SLICE + 1 : LA_SLICE + 2); }
 #define LA_S 66           // LDS row stride of the 64x64 operand tiles
 #ifndef LA_F_LATE
 #define LA_F_LATE 0       // 1: F tasks request X_k / the pre-solve copy after their partial sums instead of up front
@@ -273,7 +280,7 @@ __device__ __forceinline__ bool la_decode(const LaArgs &A, int k, int want_inv, 
         T.role = 3; T.row.kind = 0; T.row.blk = k + 2;   // R: sum of the diagonal look-ahead slices of block k+2
     } else {
         T.role = 2;
-        // slice-major, and only the ceil(k / LA_SLICE) slices that exist at this step are launched: the L tasks that have work
+        // slice-major, and only the ceil(k / la_slice_len(k)) slices that exist at this step are launched: the L tasks that have work
         // are then consecutive in dispatch order, which the hardware deals round-robin over the 8 XCDs.  (Row-major over
         // maxslice slots per row put the live tasks -- slices 0, 1 of every row early on -- at ids = 0, 1 mod 16, i.e. on TWO
         // of the eight XCDs, behind ~850 empty workgroups: at N = 4096 the L role ended at 49 us of a step whose diagonal
@@ -346,7 +353,8 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     //  together with A.dterm.  All loads of a group of four slices are independent; fixed summation order.)
     if (role == 3) {
         if (k + 2 >= nb) return 0;
-        const int nsd = (k >= 2) ? (k - 1 + LA_SLICE - 1) / LA_SLICE : 0;
+        const int sl_prev = la_slice_len(k - 1);   // the slices were written one step earlier
+        const int nsd = (k >= 2) ? (k - 1 + sl_prev - 1) / sl_prev : 0;
         const double *Dp = A.dpart + (((size_t)b * 2 + ((k + 2) & 1)) * A.maxslice) * 4096 + (size_t)w * 1024 + lane;
         double sacc[16];
 #pragma unroll
@@ -376,8 +384,9 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     // ============================== L: look-ahead partial sum of panel k+2 =============================================
     if (role == 2) {
         if (k + 2 >= nb) return 0;
-        const int j0 = la_first_panel(row) + LA_SLICE * slice;
-        int j1 = j0 + LA_SLICE;
+        const int sl_cur = la_slice_len(k);
+        const int j0 = la_first_panel(row) + sl_cur * slice;
+        int j1 = j0 + sl_cur;
         if (j1 > k) j1 = k;                       // history panels <= k-1
         if (j0 >= j1) return 0;
         v4d acc[4];
@@ -436,7 +445,8 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
         const int hist_end = head_start ? jf : k - 1;               // panels jf .. hist_end-1
         // (two slices per iteration, both requested before either is added: the loop is a chain of memory round trips --
         //  0.9 us per slice on the diagonal chain, 15 slices at the end of N = 4096; the order of the additions is unchanged)
-        const int nsum = (hist_end - jf + LA_SLICE - 1) / LA_SLICE;
+        const int sl_prev = la_slice_len(k - 1);   // the partial sums were written one step earlier
+        const int nsum = (hist_end - jf + sl_prev - 1) / sl_prev;
         const double *P0 = la_part(A, b, (k + 1) & 1, row, 0) + (size_t)w * 1024 + lane;
         int s = 0;
         // (LA_NSUM slabs per memory round trip, all 64 loads requested before the first addition -- the loop is a chain of round trips

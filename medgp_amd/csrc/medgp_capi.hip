@@ -389,7 +389,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
                 const int nMF = std::max(nt64 - (k + 2), 0), nUF = (want_mode & 1) ? k + 1 : 0, nUL = (want_mode & 1) ? k : 0;
                 *nF = nMF + nUF + 1;
                 *nLrows = (k + 2 < nt64 && k >= 1) ? nMF + nUL + 1 : 0;
-                *nsl = std::min(la.maxslice, (k + LA_SLICE - 1) / LA_SLICE);   // history slices that exist at step k
+                *nsl = std::min(la.maxslice, (k + la_slice_len(k) - 1) / la_slice_len(k));   // history slices that exist at step k
             };
             // look-ahead schedule: one launch per 64-wide step (kernels_cholinv_la.h)
             for (int k = 0; k < nt64; k++) {
