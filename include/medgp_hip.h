@@ -173,6 +173,12 @@ int medgp_fit_predict(medgp_ctx *ctx, int slot, const double *theta, int nstar, 
  * appended at :358-365 are the next rows -- medgp_test's no-update pass does one medgp_factor per patient instead of one
  * factorisation per imputed observation.  status as medgp_nlml_grad (no n > 2 guard, like GP_Regression::train). */
 int medgp_factor(medgp_ctx *ctx, int slot, const double *theta, double *L, double *z, int32_t *status);
+/* The same for nbatch patients in ONE call (one pipeline run, one read-back): entry b uses patient slots[b] and hypers
+ * theta[b*H ..); L[b] receives n_b*n_b doubles, z[b] n_b doubles (either array, or single entries, may be NULL); status[nbatch].
+ * What the cohort form of the no-update imputation pass uses (medgp_test --pan-list: one shared factorisation per patient, all
+ * patients of a chunk in one call; ref: main_one_test.cpp:287-300, :358-365, :386-399). */
+int medgp_factor_batch(medgp_ctx *ctx, int nbatch, const int32_t *slots, const double *theta, double *const *L, double *const *z,
+                       int32_t *status);
 
 /* nbatch independent (train(false) + predict ONE point) problems in one call: problem b uses patient
  * slots[b], hypers theta[b*H..), test point (meta2[b], t2[b]).  This is the inner body of the online
@@ -198,6 +204,14 @@ int medgp_kde_mode(int device, int nseries, const int64_t *off, const int32_t *c
 int medgp_kde_mode_at(int device, int nseries, const int64_t *off, const int32_t *cnt, const double *data, const int64_t *toff,
                       const int32_t *tcnt, const double *test, int weighted, double *mode, double *bw, int32_t *status,
                       double *kernel_ms);
+
+/* Route pinning.  By default the library picks the factorisation schedule of a call from the batch it is given (one workgroup per
+ * patient in two shapes, or the multi-CU look-ahead schedule for few large patients): fastest, and every schedule meets the parity
+ * bar, but the LAST BITS of a patient's results can then depend on how many batch-mates it had.  pinned != 0: every entry of every
+ * call is factored by the one 8-wave single-workgroup kernel, so a patient's results are bit-identical whatever the batch -- what a
+ * caller needs whose outputs must not depend on how patients were grouped into calls (medgp_test: a cohort run writes the same
+ * bytes as one run per patient).  The reference has no such choice: one patient per process, ref: main_one_test.cpp:45-481. */
+int medgp_pin_route(medgp_ctx *ctx, int pinned);
 
 /* block until all work queued on the context's stream is complete */
 int medgp_synchronize(medgp_ctx *ctx);

@@ -6,6 +6,7 @@ c_objective_one's constructor, `nlml_grad` of c_objective_one::compute_objective
 Fails loudly when the HIP library is missing -- there is no CPU path.
 """
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -22,7 +23,7 @@ SYMBOLS = [
     "medgp_num_hyp", "medgp_set_pi", "medgp_set_stream", "medgp_reserve", "medgp_set_patient",
     "medgp_set_patients", "medgp_set_prior", "medgp_set_priors", "medgp_host_alloc", "medgp_host_free", "medgp_nlml_grad_async",
     "medgp_wait", "medgp_nlml_grad", "medgp_nlml_grad_device", "medgp_get_factor",
-    "medgp_factor", "medgp_fit_predict", "medgp_fit_predict_batch", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
+    "medgp_factor", "medgp_factor_batch", "medgp_pin_route", "medgp_fit_predict", "medgp_fit_predict_batch", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
     "medgp_profile_kernel_name", "medgp_profile_read", "medgp_profile_reset", "medgp_kde_mode", "medgp_kde_mode_at",
 ]
 
@@ -83,6 +84,8 @@ def load():
     lib.medgp_nlml_grad_device.argtypes = [vp, C.c_int, i32p, vp, C.c_int, vp, vp, vp]
     lib.medgp_get_factor.argtypes = [vp, C.c_int, fp, fp, fp]
     lib.medgp_factor.argtypes = [vp, C.c_int, dp, dp, dp, i32p]
+    lib.medgp_factor_batch.argtypes = [vp, C.c_int, i32p, dp, C.POINTER(dp), C.POINTER(dp), i32p]
+    lib.medgp_pin_route.argtypes = [vp, C.c_int]
     lib.medgp_fit_predict.argtypes = [vp, C.c_int, dp, C.c_int, i32p, fp, fp, fp, i32p]
     lib.medgp_fit_predict_batch.argtypes = [vp, C.c_int, i32p, dp, i32p, fp, fp, fp, i32p]
     lib.medgp_synchronize.argtypes = [vp]
@@ -158,9 +161,7 @@ class Context:
         if getattr(self, "_h", None):
             self._lib.medgp_destroy(self._h)
             self._h = None
-            for p in getattr(self, "_pinned", []):
-                self._lib.medgp_host_free(p)
-            self._pinned = []
+            self._lane_refs = {}
 
     def __del__(self):
         try:
@@ -224,18 +225,23 @@ class Context:
                                              _ptr(arrs[2], C.c_uint8), _ptr(arrs[3], C.c_float), _ptr(arrs[4], C.c_float)))
 
     def pinned(self, shape, dtype):
-        """numpy array in pinned host memory (medgp_host_alloc); freed with the context."""
+        """numpy array in pinned host memory (medgp_host_alloc).  The memory belongs to the ARRAY, not to the context: it is
+        freed (medgp_host_free) when the last view of it is garbage collected, so an array a caller still holds after close()
+        stays valid.  Arrays handed to nlml_grad_async are additionally kept alive by the context until wait(lane)."""
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         p = self._lib.medgp_host_alloc(max(n, 1))
         if not p:
             raise MedgpError("medgp_host_alloc failed")
-        self._pinned = getattr(self, "_pinned", []) + [p]
         buf = (C.c_char * max(n, 1)).from_address(p)
+        weakref.finalize(buf, self._lib.medgp_host_free, p)   # every numpy view keeps `buf` alive through its .base chain
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def nlml_grad_async(self, lane, slots, theta, flag_grad, nlml, grad, status):
         """medgp_nlml_grad_async: theta / nlml / grad / status are (pinned) numpy arrays that stay alive until wait(lane)."""
         slots = np.ascontiguousarray(slots, dtype=np.int32)
+        if not hasattr(self, "_lane_refs"):
+            self._lane_refs = {}
+        self._lane_refs[int(lane)] = (theta, nlml, grad, status)   # the device writes into these until wait(lane)
         self._chk(self._lib.medgp_nlml_grad_async(self._h, int(lane), slots.shape[0], _ptr(slots, C.c_int32),
                                                   C.c_void_p(theta.ctypes.data), int(bool(flag_grad)), C.c_void_p(nlml.ctypes.data),
                                                   C.c_void_p(grad.ctypes.data if grad is not None else 0),
@@ -243,6 +249,11 @@ class Context:
 
     def wait(self, lane):
         self._chk(self._lib.medgp_wait(self._h, int(lane)))
+        getattr(self, "_lane_refs", {}).pop(int(lane), None)
+
+    def pin_route(self, pinned=True):
+        """medgp_pin_route: one factorisation kernel for every call, so a patient's bits do not depend on its batch-mates."""
+        self._chk(self._lib.medgp_pin_route(self._h, 1 if pinned else 0))
 
     def nlml_grad(self, slots, theta, flag_grad=True, keep_factor=False):
         """Host-pointer operator. theta: [nbatch, H]. Returns (nlml[nbatch], grad[nbatch,H] or None, status[nbatch]).
@@ -280,6 +291,19 @@ class Context:
         st = C.c_int32()
         self._chk(self._lib.medgp_factor(self._h, int(slot), _ptr(theta, C.c_double), _ptr(Lm, C.c_double), _ptr(z, C.c_double), C.byref(st)))
         return Lm, z, st.value
+
+    def factor_batch(self, slots, theta, ns):
+        """medgp_factor_batch: list of (L[n,n], z[n]) per entry and the status array; ns = observations of each entry."""
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        nb = slots.shape[0]
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(nb, self.H)
+        Ls = [np.zeros((int(n), int(n))) for n in ns]
+        zs = [np.zeros(int(n)) for n in ns]
+        Lp = (C.POINTER(C.c_double) * nb)(*[_ptr(a, C.c_double) for a in Ls])
+        zp = (C.POINTER(C.c_double) * nb)(*[_ptr(a, C.c_double) for a in zs])
+        st = np.zeros(nb, dtype=np.int32)
+        self._chk(self._lib.medgp_factor_batch(self._h, nb, _ptr(slots, C.c_int32), _ptr(theta, C.c_double), Lp, zp, _ptr(st, C.c_int32)))
+        return list(zip(Ls, zs)), st
 
     def fit_predict(self, slot, theta, meta2, t2):
         theta = np.ascontiguousarray(theta, dtype=np.float64)

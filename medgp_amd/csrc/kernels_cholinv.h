@@ -416,12 +416,25 @@ __device__ __forceinline__ void trail_tile(ld_t *D, int s2, int u, int t, int li
 }
 // (inlined into its callers: as an out-of-line function it claimed 248 VGPRs + 32 AGPRs for callee-saved traffic, and a kernel is
 //  allocated the maximum over its call graph -- k_la_step lost its second workgroup per CU to a callee it runs in one role)
+#ifdef LA_EXP_NOINV
+#define DFW_SETFAIL() do {} while (0)   // the garbage this diagnostic build produces must not end the factor early
+#else
+#define DFW_SETFAIL() do { if (lane == 0) *fail = 1; } while (0)
+#endif
+#ifdef LA_FSTAMPS   // diagnostic build: cumulative s_memtime stamps of wave 0 inside the four-wave factor (scratch/la_stamps.py)
+#define FST(i) do { if (fst && wave == 0 && lane == 0) fst[i] = __builtin_amdgcn_s_memtime() - fst_t0; } while (0)
+__device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t *fail, ld_t *logdet, int wave, int lane, unsigned long long *fst = nullptr) {
+    const unsigned long long fst_t0 = __builtin_amdgcn_s_memtime();
+#else
+#define FST(i) do {} while (0)
 __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t *fail, ld_t *logdet, int wave, int lane) {
+#endif
     const int li = lane & 15, g = lane >> 4;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
     if (wave == 0) {
-        if (!diag16(TD(0, 0), TX(0, 0), dv, dv + 64, lane)) { if (lane == 0) *fail = 1; }
+        if (!diag16(TD(0, 0), TX(0, 0), dv, dv + 64, lane)) { DFW_SETFAIL(); }
     }
+    FST(0);
     __syncthreads();
     if (*fail) return;
 #pragma unroll 1
@@ -433,11 +446,14 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
             tile_st(TD(s2, t), lt, li, g);
         }
         __syncthreads();
+        FST(1 + 3 * t);
         // ---- phase B
         if (wave == 0) {
             trail_tile(D, t + 1, t + 1, t, li, g);
             __builtin_amdgcn_wave_barrier();
-            if (!diag16(TD(t + 1, t + 1), TX(t + 1, t + 1), dv + 16 * (t + 1), dv + 64, lane)) { if (lane == 0) *fail = 1; }
+            FST(2 + 3 * t);
+            if (!diag16(TD(t + 1, t + 1), TX(t + 1, t + 1), dv + 16 * (t + 1), dv + 64, lane)) { DFW_SETFAIL(); }
+            FST(3 + 3 * t);
         } else if (wave < 4) {
             // remaining trailing tiles (s,u), t+1 <= u <= s <= 3, (s,u) != (t+1,t+1): dealt round-robin to waves 1..3
             int e = 0;
@@ -448,14 +464,20 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
                     e++;
                 }
             // finished inverse row t (t >= 1): tiles X(t, 0..t-1)
+#ifndef LA_EXP_NOINV   // (diagnostic build, results meaningless: prices the off-diagonal tiles of the inverse)
             if (t >= 1 && wave - 1 < t) inv_row_tiles(D, X, t, wave - 1, li, g);
+#endif
         }
         __syncthreads();
         if (*fail) return;
     }
+    FST(10);
     // ---- tail: inverse rows 3 (and row 2 was done in phase B(2))
+#ifndef LA_EXP_NOINV
     if (wave < 3) inv_row_tiles(D, X, 3, wave, li, g);
-    else if (wave == 3) {
+    else
+#endif
+    if (wave == 3) {
 #pragma unroll
         for (int t = 1; t < 4; t++)
             for (int s2 = 0; s2 < t; s2++) tile_st(TX(s2, t), zero4, li, g);   // strictly-upper tiles of X are zero
@@ -465,6 +487,7 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
         if (lane == 0) *logdet += lg;
     }
     __syncthreads();
+    FST(11);
 #undef TD
 #undef TX
 }

@@ -589,10 +589,16 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
 #pragma unroll
         for (int r = 0; r < 4; r++) sm.Xs[16 * w + 4 * r + g][16 * ct + li] = -acc[ct][r];
     __syncthreads();
+#ifdef LA_FSTAMPS
+    diag_factor_wg((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.Ls[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, w, lane, (unsigned long long *)L.slab + 2048 + 16 * k);
+#else
     diag_factor_wg((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.Ls[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, w, lane);
+#endif
     __syncthreads();
     LA_TD(6);
+#ifndef LA_EXP_NOINV
     if (sm.fail) return 1;
+#endif
     double *Xn = A.xk2 + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096;
     // (two columns per lane and store: 16-byte accesses, 8 passes instead of 16 on the tail of the chain)
     for (int e = tid; e < 64 * 32; e += LA_THREADS) {

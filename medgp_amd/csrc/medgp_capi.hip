@@ -97,6 +97,7 @@ struct medgp_ctx {
     int la_park = 256;        // MEDGP_LA_PARK=<workgroup id>|0: where the look-ahead schedule parks its sleeping workgroup (0 = off)
     int la_park_maxbatch = 8; // MEDGP_LA_PARK_MAXBATCH: largest batch the parking is used for (measured: 4 x N=2048 -5 %, 16 x N=2048 +2 %)
     int force_mc = 0;         // MEDGP_MULTI_CU=1 forces / -1 forbids the multi-CU factorisation (0 = auto)
+    int pin_route = 0;        // medgp_pin_route: every entry is factored by k_cholinv<8,4> whatever the batch (reproducible bits)
     int num_cu = 256;
     int dbg_fail = 0;         // MEDGP_DEBUG_FAIL_ATTEMPTS=k: test hook, see MedgpDev::dbg_fail
     int nsplit = 1;           // MEDGP_STREAMS=2 splits large batches over two streams (measured: 98.9k vs 104.6k evals/s -> off)
@@ -170,13 +171,15 @@ struct Launcher {
         else (void)hipEventCreate(&e);
         return e;
     }
-    ~Launcher() {
+    void finish() {   // closes the bracket now (the destructor then does nothing)
         if (on) {
             (void)hipEventRecord(b, st);
             if (kid >= 0) c->events.push_back({kid, a, b});
             else { c->ev_pool.push_back(a); c->ev_pool.push_back(b); }   // recorded but never read: safe to re-record later
+            on = false;
         }
     }
+    ~Launcher() { finish(); }
 };
 
 int drain_events(medgp_ctx *c) {
@@ -330,7 +333,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
     // N=512: 64 patients 0.60 vs 0.84, 128: 0.80 vs 0.89, 192: 1.18 vs 0.93; N=1024: 64: 2.0 vs 4.8, 128: 3.9 vs 4.9,
     // 200: 6.0 vs 5.1; N=2048: 16: 4.4 vs 32, 64: 11.4 vs 33.5.  The multi-CU time grows linearly with the batch, the
     // single-workgroup time is flat up to one patient per CU: the crossover sits near 0.6 #CU for every N >= 512.
-    const bool multi_cu = !c->use_v0 && (c->force_mc > 0 || (c->force_mc == 0 && nt64 >= 2 && nbatch <= (c->num_cu * 3) / 5));
+    const bool multi_cu = !c->use_v0 && !c->pin_route && (c->force_mc > 0 || (c->force_mc == 0 && nt64 >= 2 && nbatch <= (c->num_cu * 3) / 5));
 #ifdef MEDGP_LEGACY_AB
     if (c->use_v0) {
         launch_assemble();
@@ -421,7 +424,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         // compiled ONCE for the tightest register budget among its callers -- with a <*,2> shape (four waves per SIMD, 128 VGPRs)
         // in the library it is held to 128 VGPRs and carries 182 scratch accesses on the serial path of EVERY shape (248 VGPRs and
         // 18 without; found when the legacy k_ci_panel caller that had masked this left the build: k_cholinv<4,4> 1.37 -> 1.48 ms).
-        const int shape = c->cholinv_nw ? c->cholinv_nw : ((nbatch > c->num_cu || nt64 <= 4) ? 44 : 84);
+        const int shape = c->pin_route ? 84 : (c->cholinv_nw ? c->cholinv_nw : ((nbatch > c->num_cu || nt64 <= 4) ? 44 : 84));
         if (shape == 44) hipLaunchKernelGGL((k_cholinv<4, 4, 0>), dim3(nbatch), dim3(256), 0, stream, L, want_mode);
         else hipLaunchKernelGGL((k_cholinv<8, 4, 0>), dim3(nbatch), dim3(512), 0, stream, L, want_mode);
     }
@@ -433,7 +436,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         const int wg_tiles = tri(nt64);
         const dim3 tg(8 * ((nbatch + 7) / 8) * wg_tiles), tb(WG_THREADS);
         from_slab = 1;
-        Launcher *lw = new Launcher(c, KID_WGRAD, stream);
+        Launcher lw(c, KID_WGRAD, stream);
         switch (c->use_v0 ? 0 : L.Q) {
         case 1: hipLaunchKernelGGL(k_wgrad<1>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
         case 2: hipLaunchKernelGGL(k_wgrad<2>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
@@ -445,7 +448,8 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         case 8: hipLaunchKernelGGL(k_wgrad<8>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
         default: from_slab = 0; break;   // Q > 8 (or MEDGP_V0): generic kernels below
         }
-        if (from_slab) delete lw; else { lw->kid = -1; delete lw; }
+        if (!from_slab) lw.kid = -1;   // nothing was launched under this label: its events go back to the pool unread
+        lw.finish();
         if (!from_slab) {
             { Launcher l(c, KID_LAUUM, stream); hipLaunchKernelGGL(k_lauum_v0, dim3(tri(nt64), nbatch), dim3(256), 0, stream, L); }
             const int nbins = L.Q * tri(L.D);
@@ -847,8 +851,14 @@ int upload_priors(medgp_ctx *c, int nrows, const int32_t *slots, const uint8_t *
                   const float *p0, const float *p1) {
     const int H = c->H;
     if (flag && (!type || !is_exp || !p0 || !p1)) return fail(c, MEDGP_ERR_ARG, "prior arrays must all be given");
-    for (int k = 0; slots && k < nrows; k++)
+    std::vector<uint8_t> seen((slots && nrows > 1) ? (size_t)c->max_slots : 0, 0);
+    for (int k = 0; slots && k < nrows; k++) {
         if (slots[k] < 0 || slots[k] >= c->max_slots) return fail(c, MEDGP_ERR_CAPACITY, "slot %d outside [0, %d)", slots[k], c->max_slots);
+        if (!seen.empty()) {   // two scatter workgroups would write the same prior rows: which one wins is undefined
+            if (seen[slots[k]]) return fail(c, MEDGP_ERR_ARG, "slot %d appears twice in one medgp_set_priors", slots[k]);
+            seen[slots[k]] = 1;
+        }
+    }
     if (flag)
         for (size_t h = 0; h < (size_t)nrows * H; h++)
             if (type[h] < -1 || type[h] > 2) return fail(c, MEDGP_ERR_ARG, "prior type[%zu] = %d unsupported (KDE prior type 3 is never constructed by the reference's mains)", h, type[h]);
@@ -1114,33 +1124,74 @@ static int fit_predict_impl(medgp_ctx *c, int nbatch, const int32_t *slots, cons
     return MEDGP_OK;
 }
 
-int medgp_factor(medgp_ctx *c, int slot, const double *theta, double *Lout, double *zout, int32_t *status) {
+int medgp_factor_batch(medgp_ctx *c, int nbatch, const int32_t *slots, const double *theta, double *const *Lout, double *const *zout,
+                       int32_t *status) {
     if (!c) return MEDGP_ERR_ARG;
-    if (!theta) return fail(c, MEDGP_ERR_ARG, "theta is NULL");
+    if (!slots || !theta || nbatch < 1) return fail(c, MEDGP_ERR_ARG, "bad argument");
     if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
     HIPCHK(c, hipSetDevice(c->device));
-    int32_t s1 = slot;
     int max_n = 0, rc;
-    if ((rc = set_batch(c, 1, &s1, &max_n, true))) return rc;       // the CALLER's observation order
-    const int n = c->h_n[slot], ld = c->ldn;
-    HIPCHK(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * c->H, hipMemcpyHostToDevice, c->stream));
-    if ((rc = run_pipeline(c, 1, max_n, c->d_theta, 0, false, 1, nullptr, nullptr, nullptr, false))) return rc;
-    int st = 0;
-    HIPCHK(c, hipMemcpyAsync(&st, c->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = set_batch(c, nbatch, slots, &max_n, true))) return rc;       // the CALLER's observation order
+    const int ld = c->ldn;
+    HIPCHK(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * c->H * nbatch, hipMemcpyHostToDevice, c->stream));
+    if ((rc = run_pipeline(c, nbatch, max_n, c->d_theta, 0, false, 1, nullptr, nullptr, nullptr, false))) return rc;
+    std::vector<int> st(nbatch, 0);
+    HIPCHK(c, hipMemcpyAsync(st.data(), c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (status) *status = st;
-    if (st < 0) return MEDGP_OK;
-    if (Lout && n > 0) {
-        const char *hp = nullptr;
-        if ((rc = d2h_pinned(c, c->dev.Kmat, sizeof(double) * n * ld, &hp))) return rc;
-        const double *hl = (const double *)hp;
-        for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) Lout[(size_t)i * n + j] = (j <= i) ? hl[(size_t)i * ld + j] : 0.0;
+    if (status) for (int b = 0; b < nbatch; b++) status[b] = st[b];
+    // export: the n x ld leading rows of every successful entry, through the pinned bounce buffer in groups of <= 256 MB
+    size_t b0 = 0;
+    while (Lout && b0 < (size_t)nbatch) {
+        size_t b1 = b0, bytes = 0;
+        std::vector<size_t> off;
+        while (b1 < (size_t)nbatch) {
+            const int n = c->h_n[slots[b1]];
+            const size_t need = (st[b1] >= 0 && Lout[b1] && n > 0) ? sizeof(double) * n * ld : 0;
+            if (b1 > b0 && bytes + need > ((size_t)256 << 20)) break;
+            off.push_back(bytes); bytes += need; b1++;
+        }
+        if (bytes > c->bounce_cap) {
+            if (c->h_bounce) (void)hipHostFree(c->h_bounce);
+            c->h_bounce = nullptr; c->bounce_cap = 0;
+            HIPCHK(c, hipHostMalloc((void **)&c->h_bounce, bytes + bytes / 4, hipHostMallocDefault));
+            c->bounce_cap = bytes + bytes / 4;
+        }
+        for (size_t b = b0; b < b1; b++) {
+            const int n = c->h_n[slots[b]];
+            if (st[b] >= 0 && Lout[b] && n > 0)
+                HIPCHK(c, hipMemcpyAsync(c->h_bounce + off[b - b0], c->dev.Kmat + b * (size_t)ld * ld, sizeof(double) * n * ld, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (size_t b = b0; b < b1; b++) {
+            const int n = c->h_n[slots[b]];
+            if (!(st[b] >= 0 && Lout[b] && n > 0)) continue;
+            const double *hl = (const double *)(c->h_bounce + off[b - b0]);
+            double *Lo = Lout[b];
+            for (int i = 0; i < n; i++)
+                for (int j = 0; j < n; j++) Lo[(size_t)i * n + j] = (j <= i) ? hl[(size_t)i * ld + j] : 0.0;
+        }
+        b0 = b1;
     }
-    if (zout && n > 0) {
-        HIPCHK(c, hipMemcpyAsync(zout, c->dev.z, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    if (zout) {
+        for (int b = 0; b < nbatch; b++) {
+            const int n = c->h_n[slots[b]];
+            if (st[b] >= 0 && zout[b] && n > 0)
+                HIPCHK(c, hipMemcpyAsync(zout[b], c->dev.z + (size_t)b * ld, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return MEDGP_OK;
+}
+
+int medgp_factor(medgp_ctx *c, int slot, const double *theta, double *Lout, double *zout, int32_t *status) {
+    int32_t s1 = slot;
+    double *Lp[1] = {Lout}, *zp[1] = {zout};
+    return medgp_factor_batch(c, 1, &s1, theta, Lout ? Lp : nullptr, zout ? zp : nullptr, status);
+}
+
+int medgp_pin_route(medgp_ctx *c, int pinned) {
+    if (!c) return MEDGP_ERR_ARG;
+    c->pin_route = pinned ? 1 : 0;
     return MEDGP_OK;
 }
 

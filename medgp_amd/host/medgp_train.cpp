@@ -30,6 +30,7 @@
 #include "medgp_experiment.hpp"
 #include "medgp_host.hpp"
 #include "medgp_optimizer.hpp"
+#include "medgp_workpool.hpp"
 
 using namespace medgp;
 using std::cout;
@@ -51,79 +52,6 @@ struct Patient {
     scg_machine scg;
     varem_machine vem;
     bool use_vem = false, active = false;
-};
-
-// host cores this process may use: hardware threads capped by the cgroup CPU quota (a box with many more hardware threads
-// than quota must not get one worker per hardware thread)
-int usable_cores() {
-    int n = (int)std::thread::hardware_concurrency();
-    if (n < 1) n = 1;
-    std::ifstream f("/sys/fs/cgroup/cpu.max");
-    string q;
-    long long per = 0;
-    if (f >> q >> per && q != "max" && per > 0) n = std::min<long long>(n, std::max<long long>(1, atoll(q.c_str()) / per));
-    return std::max(1, std::min(n, 64));
-}
-
-// Persistent worker threads for the per-patient host work (file loading, optimiser state machines).  Workers BLOCK on a condition
-// variable between jobs -- no spinning (an OpenMP team's spinning workers starved the HIP runtime under the box's cgroup quota).
-class WorkPool {
-public:
-    explicit WorkPool(int nthreads) {
-        for (int i = 1; i < nthreads; i++) workers.emplace_back([this] { loop(); });
-    }
-    ~WorkPool() {
-        { std::lock_guard<std::mutex> l(m); stop = true; }
-        cv.notify_all();
-        for (auto &t : workers) t.join();
-    }
-    // fn(i) for i in [0, n), dynamically dealt in chunks; returns when all are done (the caller works too)
-    void parallel_for(int n, const std::function<void(int)> &fn) {
-        if (n <= 0) return;
-        if (workers.empty() || n == 1) { for (int i = 0; i < n; i++) fn(i); return; }
-        {
-            std::lock_guard<std::mutex> l(m);
-            job = &fn; total = n; next.store(0); pending = (int)workers.size(); gen++;
-        }
-        cv.notify_all();
-        run();
-        std::unique_lock<std::mutex> l(m);
-        done_cv.wait(l, [this] { return pending == 0; });
-        job = nullptr;
-    }
-    int size() const { return (int)workers.size() + 1; }
-
-private:
-    void run() {
-        const int chunk = std::max(1, total / (8 * ((int)workers.size() + 1)));
-        while (true) {
-            const int i0 = next.fetch_add(chunk);
-            if (i0 >= total) break;
-            for (int i = i0; i < std::min(total, i0 + chunk); i++) (*job)(i);
-        }
-    }
-    void loop() {
-        unsigned long long seen = 0;
-        while (true) {
-            {
-                std::unique_lock<std::mutex> l(m);
-                cv.wait(l, [&] { return stop || gen != seen; });
-                if (stop) return;
-                seen = gen;
-            }
-            run();
-            { std::lock_guard<std::mutex> l(m); pending--; }
-            done_cv.notify_one();
-        }
-    }
-    std::vector<std::thread> workers;
-    std::mutex m;
-    std::condition_variable cv, done_cv;
-    const std::function<void(int)> *job = nullptr;
-    std::atomic<int> next{0};
-    int total = 0, pending = 0;
-    unsigned long long gen = 0;
-    bool stop = false;
 };
 
 // prior descriptors of several patients in ONE transfer (medgp_set_priors): every variational-EM outer iteration changes psi of
@@ -151,9 +79,10 @@ bool upload_priors(medgp_ctx *ctx, const vector<Patient *> &ps, int H, WorkPool 
 
 }  // namespace
 
-int main(int argc, const char *argv[]) {
+static int train_main(int argc, const char *argv[]) {
     string exp_cfg, pan_arg, pan_list;
     int thread_num = 1, device = 0, max_batch = 1024, host_threads = 0, pingpong_min = 1024;
+    bool pin_route = false;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--cfg") && i + 1 < argc) exp_cfg = argv[++i];
         else if (!strcmp(argv[i], "--pan") && i + 1 < argc) pan_arg = argv[++i];
@@ -163,6 +92,7 @@ int main(int argc, const char *argv[]) {
         else if (!strcmp(argv[i], "--max-batch") && i + 1 < argc) max_batch = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--host-threads") && i + 1 < argc) host_threads = atoi(argv[++i]);   // 0 = usable cores (<= 8)
         else if (!strcmp(argv[i], "--pingpong-min") && i + 1 < argc) pingpong_min = atoi(argv[++i]);   // active patients from which the lock-step loop splits them in two alternating halves
+        else if (!strcmp(argv[i], "--pin-route")) pin_route = true;   // medgp_pin_route: bit-identical results whatever the batch (slower for few large patients)
         else { cout << "Error: unknown argument: " << argv[i] << endl; return 1; }
     }
     if (exp_cfg.empty() || (pan_arg.empty() && pan_list.empty())) {
@@ -240,6 +170,7 @@ int main(int argc, const char *argv[]) {
             max_batch = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(std::max(1, max_batch), want), fit));
         }
         if (medgp_reserve(ctx, nslot, max_n, max_batch)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
+        if (pin_route && medgp_pin_route(ctx, 1)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
         // packed SoA cohort arrays (stacked meta / t / y with offsets)
         vector<int32_t> slots(live.size());
         vector<int64_t> offs(live.size() + 1, 0);
@@ -363,6 +294,8 @@ int main(int argc, const char *argv[]) {
         });
     };
     for (Group &g : groups) fill_requests(g);
+    const size_t groups_initial = groups.size();
+    int merges = 0;
     auto submit = [&](Group &g, int lane) -> bool {   // queue the evaluation of the group's pending requests
         g.nb = (int)g.mem.size();
         if (g.nb == 0) return true;
@@ -408,8 +341,39 @@ int main(int argc, const char *argv[]) {
         std::deque<int> ready;
         for (int g = 0; g < (int)groups.size(); g++) ready.push_back(g);
         int free_lanes[2] = {1, 1};
+        // Re-forming: groups are cut once, from the active set at the start; patients finish at different times (early stop of the
+        // variational-EM outer loop, ref: util/c_optimizer_varEM.cpp:89-95; line-search failures, ref: util/c_optimizer_scg.cpp:125-131),
+        // and once what is left fits ONE launch that no longer fills the chip twice over, two half-empty launches per step are
+        // slower than one.  When that point is reached nothing new is queued until the device is idle, then the groups are merged.
+        auto want_merge = [&]() {
+            size_t act = 0, nonempty = 0;
+            for (const Group &g : groups) { act += g.mem.size(); nonempty += g.mem.empty() ? 0 : 1; }
+            return nonempty >= 2 && (int)act <= max_batch && (int)act < 2 * std::max(1, pingpong_min);
+        };
         while (!ready.empty() || !inflight.empty()) {
-            while (!ready.empty() && (free_lanes[0] || free_lanes[1])) {
+            if (inflight.empty() && groups.size() > 1 && want_merge()) {
+                Group mg;
+                for (Group &g : groups) mg.mem.insert(mg.mem.end(), g.mem.begin(), g.mem.end());
+                const size_t cap = mg.mem.size();
+                mg.th = (double *)medgp_host_alloc(sizeof(double) * cap * H);
+                mg.nl = (double *)medgp_host_alloc(sizeof(double) * cap);
+                mg.gr = (double *)medgp_host_alloc(sizeof(double) * cap * H);
+                mg.st = (int32_t *)medgp_host_alloc(sizeof(int32_t) * cap);
+                if (!mg.th || !mg.nl || !mg.gr || !mg.st) { cout << "ERROR: pinned host allocation failed" << endl; return 1; }
+                size_t w = 0;
+                for (Group &g : groups) {   // the pending request rows travel with their patients
+                    if (!g.mem.empty()) std::memcpy(mg.th + w * H, g.th, sizeof(double) * g.mem.size() * H);
+                    w += g.mem.size();
+                    medgp_host_free(g.th); medgp_host_free(g.nl); medgp_host_free(g.gr); medgp_host_free(g.st);
+                }
+                cout << "INFO: " << groups.size() << " groups merged into one of " << cap << " active patients" << endl;
+                merges++;
+                groups.clear();
+                groups.push_back(std::move(mg));
+                ready.clear();
+                ready.push_back(0);
+            }
+            while (!ready.empty() && (free_lanes[0] || free_lanes[1]) && !(groups.size() > 1 && !inflight.empty() && want_merge())) {
                 const int g = ready.front(); ready.pop_front();
                 const int lane = free_lanes[0] ? 0 : 1;
                 const auto t0 = now();
@@ -436,7 +400,7 @@ int main(int argc, const char *argv[]) {
     const double t_loop = secs(t_loop0, now());
     cout << "optimization finished: " << total_evals << " nlml+grad evaluations in " << steps << " lock-step batches" << endl;
     cout << "INFO: lock-step optimisation: " << t_loop << " s wall (" << t_wait << " s waiting for the device, " << t_host
-         << " s in the host optimiser on " << pool.size() << " threads, " << groups.size() << " group(s))" << endl;
+         << " s in the host optimiser on " << pool.size() << " threads, " << groups_initial << " group(s)" << (merges ? ", merged into one when the active set had shrunk" : "") << ")" << endl;
 
     // ---------------- outputs (ref :297-323)
     for (auto &pp : pts) {
@@ -459,4 +423,18 @@ int main(int argc, const char *argv[]) {
     time(&t_end);
     cout << "Finish all jobs. Total elapsed time = " << difftime(t_end, t_start) << " seconds" << endl;
     return 0;
+}
+
+// exceptions of the host side (bad_alloc, a throwing loader on a worker thread: WorkPool rethrows them on the calling thread)
+// end the run with the reference's error convention -- an ERROR line and a non-zero exit code -- not with std::terminate
+int main(int argc, const char *argv[]) {
+    try {
+        return train_main(argc, argv);
+    } catch (const std::exception &e) {
+        cout << "ERROR: " << e.what() << endl;
+        return 1;
+    } catch (...) {
+        cout << "ERROR: unknown exception" << endl;
+        return 1;
+    }
 }

@@ -1,10 +1,22 @@
 #!/usr/bin/env python3
-"""Cohort training across the GPUs of one node: one process per GPU (torch.distributed), the patient list is
-partitioned with the LPT rule of medgp_amd.shard (no data-path collective -- patients are independent, the
-reference fans them out as one SLURM job per patient, ref: medgpc/util/run_exp_generator.py:213-260), every rank
-runs the lock-step trainer `medgp_train --pan-list <its shard> --device <local rank>`.
+"""Cohort training across the GPUs of one node: one process per GPU (torch.distributed), no data-path collective --
+patients are independent; the reference fans them out as one scheduler job per patient and the scheduler balances them
+dynamically (ref: medgpc/util/run_exp_generator.py:213-260, scripts/slurm_della.json:6-62).  Every rank runs the lock-step
+trainer `medgp_train --pan-list <chunk> --device <local rank>`.
 
-The ONE collective (optional, --gather): after training, the per-patient hyper vectors train_hyp_<PAN>.bin are
+Scheduling (--schedule):
+  dynamic (default)  the patient list is sorted by the cost model of medgp_amd.shard (N^3 + c Q N^2), longest first, and cut
+                     into chunks of --chunk patients (default 256 = one patient per CU); ranks PULL the next chunk from a shared
+                     counter (a flock-protected file in exp_train_dir: no process group exists while the trainers run).  The
+                     cost model cannot know how many evaluations a patient will take -- the variational-EM loop stops early on
+                     a relative loss change < 0.5 % (ref: util/c_optimizer_varEM.cpp:89-95), SCG line searches fail
+                     (ref: util/c_optimizer_scg.cpp:125-131) -- so a static partition leaves ranks idle behind the slowest
+                     shard; with a queue a rank that finishes early simply takes more chunks.
+  static             one LPT shard per rank, fixed before the first evaluation (rounds 1-3).
+A patient's results do not depend on which rank or chunk trained it (same kernels for the same batch-size class; pass
+--pin-route to the trainer through --exe-args for bit-identity across batch-size classes as well).
+
+The ONE collective on data (optional, --gather): after training, the per-patient hyper vectors train_hyp_<PAN>.bin are
 all-gathered (RCCL over xGMI under the nccl backend, gloo on CPU) into <exp_train_dir>/cohort_train_hyp.npy --
 the input of the cohort-level kernel clustering step (ref: medgpc/util/binaryIO.py:20-35 read_train_kernel).
 
@@ -12,10 +24,12 @@ the input of the cohort-level kernel clustering step (ref: medgpc/util/binaryIO.
         -m medgp_amd.train_cohort --cfg exp_setup.json --pan-list pans.txt --gather
 """
 import argparse
+import fcntl
 import json
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 
@@ -37,16 +51,42 @@ def count_observations(cfg, pan):
     return n
 
 
+def take_ticket(path):
+    """Atomic fetch-and-increment of the integer in `path` (created on first use): the shared chunk counter."""
+    fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o644)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX)
+        raw = os.read(fd, 32)
+        k = int(raw) if raw.strip() else 0
+        os.lseek(fd, 0, os.SEEK_SET)
+        os.ftruncate(fd, 0)
+        os.write(fd, str(k + 1).encode())
+        return k
+    finally:
+        fcntl.flock(fd, fcntl.LOCK_UN)
+        os.close(fd)
+
+
+def make_chunks(ns, chunk, Q):
+    """Patients longest-first (cost model of shard.cost, ties by index), cut into chunks of `chunk`."""
+    ns = np.asarray(ns)
+    order = np.lexsort((np.arange(ns.shape[0]), -shard.cost(ns, Q)))
+    return [order[i:i + chunk].tolist() for i in range(0, len(order), max(1, chunk))]
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", required=True)
     ap.add_argument("--pan-list", required=True)
     ap.add_argument("--exe", default=DEFAULT_EXE)
+    ap.add_argument("--exe-args", default="", help="extra arguments for the trainer, e.g. '--pin-route'")
     ap.add_argument("--gather", action="store_true")
     ap.add_argument("--backend", default=None, help="nccl (default with GPUs) or gloo")
     ap.add_argument("--max-batch", type=int, default=1024)
+    ap.add_argument("--schedule", choices=("dynamic", "static"), default="dynamic")
+    ap.add_argument("--chunk", type=int, default=256, help="patients per work-queue chunk (dynamic schedule)")
     ap.add_argument("--timeout-hours", type=float, default=48.0,
-                    help="process-group timeout: how long a finished rank waits for the slowest shard")
+                    help="process-group timeout: how long a finished rank waits for the slowest one")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -57,18 +97,43 @@ def main(argv=None):
     cfg = json.load(open(args.cfg))
     pans = [p for p in open(args.pan_list).read().split() if p]
     ns = [count_observations(cfg, p) for p in pans]
-    parts = shard.lpt_partition(ns, world, Q=int(cfg["Q"]))
-    mine = [pans[i] for i in parts[rank]]
-    rc = 0
-    if mine:
-        shard_file = os.path.join(cfg["exp_train_dir"], f"pan_shard_rank{rank}.txt")
+    extra = args.exe_args.split()
+
+    def run_trainer(idx, tag):
+        shard_file = os.path.join(cfg["exp_train_dir"], f"pan_{tag}.txt")
         with open(shard_file, "w") as f:
-            f.write("\n".join(mine) + "\n")
+            f.write("\n".join(pans[i] for i in idx) + "\n")
         r = subprocess.run([args.exe, "--cfg", args.cfg, "--pan-list", shard_file, "--device", str(local_rank),
-                            "--max-batch", str(args.max_batch)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        rc = r.returncode
-        with open(os.path.join(cfg["exp_train_dir"], f"train_rank{rank}.log"), "w") as f:
+                            "--max-batch", str(args.max_batch)] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        with open(os.path.join(cfg["exp_train_dir"], f"train_{tag}.log"), "w") as f:
             f.write(r.stdout)
+        return r.returncode
+
+    rc = 0
+    mine = []          # global indices of the patients this rank trained
+    t_busy = 0.0
+    if args.schedule == "static" or world == 1:
+        parts = shard.lpt_partition(ns, world, Q=int(cfg["Q"]))
+        mine = [int(i) for i in parts[rank]]
+        if mine:
+            t0 = time.perf_counter()
+            rc = run_trainer(mine, f"shard_rank{rank}")
+            t_busy = time.perf_counter() - t0
+    else:
+        chunks = make_chunks(ns, args.chunk, int(cfg["Q"]))
+        # one counter per launch: all ranks of a node are children of the same launcher process
+        qfile = os.path.join(cfg["exp_train_dir"], f".chunk_queue_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+        while True:
+            k = take_ticket(qfile)
+            if k >= len(chunks):
+                break
+            t0 = time.perf_counter()
+            rc = max(rc, run_trainer(chunks[k], f"chunk{k:04d}_rank{rank}"))
+            t_busy += time.perf_counter() - t0
+            mine += [int(i) for i in chunks[k]]
+        mine.sort()
+    with open(os.path.join(cfg["exp_train_dir"], f"train_rank{rank}.busy"), "w") as f:
+        f.write(f"{t_busy:.6f} {len(mine)}\n")
     if world > 1:
         # The process group is created only now, AFTER the training subprocess has returned: lock-step SCG runs until the
         # slowest patient of a shard finishes, so ranks can arrive hours apart, and a group created up front would have its
@@ -89,9 +154,11 @@ def main(argv=None):
             H = int(cfg["D"]) + int(cfg["Q"]) * (int(cfg["D"]) * int(cfg["R"]) + 2 + int(cfg["D"])) if int(cfg["kernel_index"]) == 7 \
                 else (1 + 3 * int(cfg["Q"]) if int(cfg["kernel_index"]) == 8 else 3)
             # fixed-size contribution per rank: rows of (global patient index, flag, theta); absent rows are NaN
-            rows = max(len(p) for p in parts)
+            cnt = torch.tensor([len(mine)], dtype=torch.int64, device=dev)
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+            rows = max(int(cnt.item()), 1)
             buf = torch.full((rows, H + 2), float("nan"), dtype=torch.float64, device=dev)
-            for k, gi in enumerate(parts[rank]):
+            for k, gi in enumerate(mine):
                 pan = pans[gi]
                 fn = os.path.join(cfg["exp_train_dir"], f"train_hyp_{pan}.bin")
                 buf[k, 0] = float(gi)
@@ -111,6 +178,11 @@ def main(argv=None):
                 np.save(os.path.join(cfg["exp_train_dir"], "cohort_train_hyp.npy"), allrows)
         dist.barrier()
         dist.destroy_process_group()
+        if rank == 0 and args.schedule == "dynamic":
+            try:
+                os.remove(qfile)
+            except OSError:
+                pass
     return rc
 
 

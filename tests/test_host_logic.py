@@ -67,7 +67,7 @@ def test_train_cohort_launcher_shards_and_gathers_over_gloo(tmp_path):
     env = dict(os.environ, PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", "29547", "-m", "medgp_amd.train_cohort",
-                          "--cfg", ex["cfg"], "--pan-list", str(plist), "--gather", "--backend", "gloo",
+                          "--cfg", ex["cfg"], "--pan-list", str(plist), "--gather", "--backend", "gloo", "--schedule", "static",
                           "--exe", os.path.join(ROOT, "tests", "gloo_train_cohort_worker.sh")],
                          env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout + out.stderr
@@ -79,3 +79,71 @@ def test_train_cohort_launcher_shards_and_gathers_over_gloo(tmp_path):
         assert np.array_equal(got[k, 2:], exp)
     shards = [open(os.path.join(ex["dirs"]["train"], f"pan_shard_rank{r}.txt")).read().split() for r in range(2)]
     assert sorted(shards[0] + shards[1]) == pans and shards[0] and shards[1]
+
+
+def test_train_cohort_dynamic_queue_balances_skewed_budgets_over_gloo(tmp_path):
+    """Ranks pull chunks of patients from a shared counter: with half of the patients ten times as expensive as the cost model
+    thinks (evaluation budgets are not known up front: early stops, failed line searches), both ranks stay busy to the end --
+    max / mean busy time <= 1.15 -- and the gathered result equals the static schedule's."""
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from exp_fixture import make_experiment
+    pans = [f"P{k:03d}" for k in range(32)]
+    ex = make_experiment(tmp_path, pans, D=2, Q=2, R=2, N=[20 + (k % 5) for k in range(32)])
+    plist = tmp_path / "pans.txt"
+    plist.write_text("\n".join(pans) + "\n")
+    # the expensive half: every patient whose N is largest -- exactly the ones a longest-first order hands out first
+    heavy = [p for k, p in enumerate(pans) if k % 5 >= 3] + pans[:3]
+    env = dict(os.environ, PYTHONPATH=ROOT, MEDGP_FAKE_UNIT="0.03", MEDGP_FAKE_HEAVY=" ".join(heavy))
+    results = {}
+    for schedule, port in (("dynamic", "29551"), ("static", "29553")):
+        for f in os.listdir(ex["dirs"]["train"]):
+            os.remove(os.path.join(ex["dirs"]["train"], f))
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                              "--master-addr", "127.0.0.1", "--master-port", port, "-m", "medgp_amd.train_cohort",
+                              "--cfg", ex["cfg"], "--pan-list", str(plist), "--gather", "--backend", "gloo", "--schedule", schedule,
+                              "--chunk", "2", "--exe", os.path.join(ROOT, "tests", "gloo_train_cohort_worker.sh")],
+                             env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert out.returncode == 0, out.stdout + out.stderr
+        busy = [[float(v) for v in open(os.path.join(ex["dirs"]["train"], f"train_rank{r}.busy")).read().split()] for r in range(2)]
+        results[schedule] = (np.load(os.path.join(ex["dirs"]["train"], "cohort_train_hyp.npy")), busy)
+        assert int(busy[0][1] + busy[1][1]) == 32
+    got, busy = results["dynamic"]
+    np.testing.assert_array_equal(got, results["static"][0])          # same patients, same bytes, whoever trained them
+    assert got.shape[0] == 32 and np.all(got[:, 1] == 1)
+    t = np.array([b[0] for b in busy])
+    assert t.max() / t.mean() <= 1.15, (busy, results["static"][1])
+    assert not any(f.startswith(".chunk_queue_") for f in os.listdir(ex["dirs"]["train"]))   # the counter is removed at the end
+
+
+def test_test_cohort_launcher_cost_model_and_gloo_run(tmp_path):
+    """medgp_amd.test_cohort: cost model = sum N_tt^3 over the 72-h windows + n^3; LPT shards over 2 gloo ranks with a stand-in
+    tester; a failing shard makes every rank return non-zero."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from exp_fixture import make_experiment
+    from medgp_amd import test_cohort
+    # three observations at t = 0, 1, 1 and one at t = 100: N_i = 0, 2, 2 (before + same time), 0 (window) -> 16 + 4^3
+    assert test_cohort.test_cost(np.array([0.0, 1.0, 1.0, 100.0])) == 16.0 + 64.0
+    assert test_cohort.test_cost(np.zeros(0)) == 0.0
+    assert test_cohort.lpt([5.0, 1.0, 4.0, 1.0], 2) == [[0, 3], [1, 2]]
+    pans = [f"T{k:02d}" for k in range(5)]
+    ex = make_experiment(tmp_path, pans, D=2, Q=2, R=2, N=[20, 44, 24, 40, 30])
+    import json
+    cfg = json.load(open(ex["cfg"]))
+    assert test_cohort.read_times(cfg, "T01").size == 44
+    for names, want_rc in ((pans, 0), (pans[:4] + ["FAIL"], 3)):
+        plist = tmp_path / "tpans.txt"
+        plist.write_text("\n".join(names) + "\n")
+        if "FAIL" in names:
+            os.makedirs(os.path.join(ex["dirs"]["data"], "FAIL"), exist_ok=True)
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                              "--master-addr", "127.0.0.1", "--master-port", "29557", "-m", "medgp_amd.test_cohort",
+                              "--cfg", ex["cfg"], "--pan-list", str(plist), "--fold", "0", "--kernclust-alg", "gmm", "--backend", "gloo",
+                              "--exe", os.path.join(ROOT, "tests", "gloo_test_cohort_worker.sh")],
+                             env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert (out.returncode != 0) == (want_rc != 0), out.stdout + out.stderr
+        shards = [open(os.path.join(ex["dirs"]["test"], f"pan_shard_fold0_rank{r}.txt")).read().split() for r in range(2)]
+        assert sorted(shards[0] + shards[1]) == sorted(names) and shards[0] and shards[1]
+        if want_rc == 0:
+            for p in pans:
+                assert open(os.path.join(ex["dirs"]["test"], f"test_mean_w_update_flag_{p}.txt")).read() == "1\n"

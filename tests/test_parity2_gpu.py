@@ -40,7 +40,8 @@ def test_config5_full_size_vs_fixture():
 def test_headline_workload_deterministic():
     """The bench workload itself: 512 patients x N=512, D=24, Q=5, R=8, hier-gamma prior, ONE call of 512 evaluations
     (more entries than CUs: the one-workgroup-per-patient factorisation k_cholinv<4,4>, several passes per step).
-    Eight patients spread over the batch (first / last / both halves of the XCD groups) against the oracle."""
+    Every 8th patient plus the XCD-group / pass-boundary positions -- 70 of the 512 -- against the oracle (blocked gradient
+    form, which test_oracle.py ties to the per-hyper loop of the reference; the oracle calls run on a thread pool)."""
     D, N, Q, R, P, seed = 24, 512, 5, 8, 512, 2024      # bench.py's defaults
     pts, th = synth.cohort(seed, P, D, N, Q=Q, R=R)
     ctx = medgp_amd.Context(7, Q, D, R)
@@ -50,8 +51,12 @@ def test_headline_workload_deterministic():
     nlml, grad, st = ctx.nlml_grad(np.arange(P), th, True)
     assert np.all(st == 0) and np.all(np.isfinite(nlml)) and np.all(np.isfinite(grad))
     pr = O.Prior.hier_gamma(Q, D, R, 0.01, 0.01)
-    for p in (0, 1, 63, 64, 255, 256, 389, 511):
-        ref = O.nlml_grad(7, Q, D, R, *pts[p], th[p], prior=pr, nthreads=8)
+    from concurrent.futures import ThreadPoolExecutor
+    sample = sorted(set(range(0, P, 8)) | {1, 63, 255, 389, 511, 257})
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:     # ctypes releases the GIL during the oracle call
+        refs = list(ex.map(lambda p: O.nlml_grad(7, Q, D, R, *pts[p], th[p], prior=pr, nthreads=1), sample))
+    assert len(sample) >= 64
+    for p, ref in zip(sample, refs):
         assert ref["status"] == 0
         assert_parity(nlml[p], grad[p], ref, f"p{p}")
     ctx.close()

@@ -103,23 +103,40 @@ def test_single_output_kernels(kidx, Q):
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "appendixA_*.npz"))))
 def test_golden_fixtures(path):
-    """Committed vectors: inputs of the survey's reference run; expected = oracle fp64 (tight) and the
-    compiled reference's recorded fp32 nlml (its own noise floor, 1e-6)."""
+    """Committed vectors: inputs of the survey's reference run; expected = oracle fp64 (tight).  (The fp32 scalars the survey
+    session recorded from a shimmed-header build of the reference are in the same files; they are NOT evidence and are only
+    looked at by test_recorded_fp32_reference_scalars_not_evidence below.)"""
     g = np.load(path)
     D, N, Q, R = int(g["D"]), int(g["N"]), int(g["Q"]), int(g["R"])
     ctx = make_ctx(7, Q, D, R, [(g["meta"], g["t"], g["y"])])
     nlml, grad, st = ctx.nlml_grad([0], g["theta"][None, :], True)
     assert st[0] == 0
     assert abs(nlml[0] - float(g["oracle_nlml"])) <= NLML_RTOL * abs(nlml[0])
-    assert abs(nlml[0] - float(g["ref_fp32_nlml"])) <= 1e-6 * abs(nlml[0])
     if "oracle_grad" in g:
         assert_parity(nlml[0], grad[0], {"nlml": float(g["oracle_nlml"]), "grad": g["oracle_grad"]})
     if "oracle_nlml_prior2" in g:
         ctx.set_prior(0, *synth.hier_gamma_prior(Q, D, R, 0.01))
         n2, g2, _ = ctx.nlml_grad([0], g["theta"][None, :], True)
         assert_parity(n2[0], g2[0], {"nlml": float(g["oracle_nlml_prior2"]), "grad": g["oracle_grad_prior2"]})
-        assert abs(n2[0] - float(g["ref_fp32_nlml_prior2"])) <= 1e-6 * abs(n2[0])
     ctx.close()
+
+
+def test_recorded_fp32_reference_scalars_not_evidence():
+    """RECORDED, NOT EVIDENCE.  Five nlml scalars printed by the reference in the survey session (a build that needed a stand-in
+    mkl.h, which this project may not reproduce) sit in the appendixA fixtures.  They pin nothing -- parity rests on the
+    reference-derived Gram fixtures, the oracle and the finite-difference tests -- and this test only keeps the record honest:
+    the device values stay within the reference's own fp32 noise floor (1e-6) of them."""
+    for path in sorted(glob.glob(os.path.join(GOLD, "appendixA_*.npz"))):
+        g = np.load(path)
+        D, N, Q, R = int(g["D"]), int(g["N"]), int(g["Q"]), int(g["R"])
+        ctx = make_ctx(7, Q, D, R, [(g["meta"], g["t"], g["y"])])
+        nlml, _, st = ctx.nlml_grad([0], g["theta"][None, :], False)
+        assert st[0] == 0 and abs(nlml[0] - float(g["ref_fp32_nlml"])) <= 1e-6 * abs(nlml[0])
+        if "ref_fp32_nlml_prior2" in g:
+            ctx.set_prior(0, *synth.hier_gamma_prior(Q, D, R, 0.01))
+            n2, _, _ = ctx.nlml_grad([0], g["theta"][None, :], False)
+            assert abs(n2[0] - float(g["ref_fp32_nlml_prior2"])) <= 1e-6 * abs(n2[0])
+        ctx.close()
 
 
 def test_failure_semantics():
@@ -271,8 +288,11 @@ def test_baseline_config2_full_size():
     ctx = make_ctx(7, Q, D, R, pts)
     nlml, grad, st = ctx.nlml_grad(np.arange(P), th, True)
     assert np.all(st == 0) and np.all(np.isfinite(nlml)) and np.all(np.isfinite(grad))
-    for p in (0, 17, 255):
-        ref = O.nlml_grad(7, Q, D, R, *pts[p], th[p])
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:     # ALL 256 patients against the oracle
+        refs = list(ex.map(lambda p: O.nlml_grad(7, Q, D, R, *pts[p], th[p]), range(P)))
+    for p, ref in enumerate(refs):
+        assert ref["status"] == 0
         assert_parity(nlml[p], grad[p], ref, f"p{p}")
     ctx.close()
 

@@ -98,3 +98,44 @@ def test_online_imputation_matches_oracle_loop(tmp_path, built_lib):
         # the CI flag may legitimately differ only where |error| sits within float rounding of the bound
         diff = [k for k in range(len(gc)) if gc[k] != ci[k]]
         assert len(diff) <= 1, diff
+
+
+def test_cohort_list_is_byte_identical_to_one_run_per_patient(tmp_path, built_lib):
+    """medgp_test --pan-list (hyper trajectories of all patients in lock step, one shared factorisation call, all imputation
+    problems of the cohort packed into batches) writes exactly the bytes that one `medgp_test --pan` run per patient writes:
+    three patients of different sizes, one of them with too few samples for any update (ref: main_one_test.cpp:308, the
+    n > 2 guard of util/c_objective_one.cpp:51) and a different batch cap, in both passes."""
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", HOST, "medgp_test"])
+    Q, D, R = 3, 2, 2
+    pans = ["P101", "P102", "P103"]
+    ex = make_experiment(tmp_path, pans, D=D, Q=Q, R=R, N=[46, 5, 70], opt={"online_learn_rate": 1e-4})
+    mode = synth.theta(9, 0, 7, Q, D, R)
+    mode[D + 1] = 0.0
+    fold_dir = os.path.join(ex["dirs"]["kernel"], "fold0")
+    os.makedirs(fold_dir)
+    open(os.path.join(fold_dir, "gmm_mode_mixture_num.txt"), "w").write(f"{Q}\n")
+    mode.tofile(os.path.join(fold_dir, "gmm_mode_param.bin"))
+    plist = tmp_path / "pans.txt"
+    plist.write_text("\n".join(pans) + "\n")
+    base = [EXE, "--cfg", ex["cfg"], "--thread", "1", "--fold", "0", "--kernclust-alg", "gmm"]
+    r = subprocess.run(base + ["--pan-list", str(plist), "--max-batch", "64"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "lock-step rounds" in r.stdout and "3 patient(s)" in r.stdout
+    tdir = ex["dirs"]["test"]
+    cohort = {f: open(os.path.join(tdir, f), "rb").read() for f in sorted(os.listdir(tdir)) if f.startswith("test_")}
+    assert len(cohort) >= 2 * (6 + 6 + 6) - 10      # three patients x two passes x (feature, etime, ci, error, pred, flag)
+    for f in cohort:
+        os.remove(os.path.join(tdir, f))
+    for pan in pans:
+        r1 = subprocess.run(base + ["--pan", pan, "--max-batch", "16"], capture_output=True, text=True, timeout=600)
+        assert r1.returncode == 0, r1.stdout[-3000:] + r1.stderr[-2000:]
+    single = {f: open(os.path.join(tdir, f), "rb").read() for f in sorted(os.listdir(tdir)) if f.startswith("test_")}
+    assert sorted(single) == sorted(cohort)
+    for f in cohort:
+        assert cohort[f] == single[f], f
+    # and the cohort's values are the oracle loop's (the single-patient test above pins the arithmetic; here one more patient)
+    m, t, y = loaded(ex, "P103", D)
+    feat, ci, et, err, pred = reference_loop(m, t, y, mode, Q, D, R, True, 1e-4, 0.9, ex["feature_index"])
+    gp = np.frombuffer(cohort["test_mean_w_update_pred_P103.bin"], np.float64)
+    np.testing.assert_allclose(gp, pred, rtol=2e-5, atol=2e-6)
