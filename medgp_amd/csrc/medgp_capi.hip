@@ -328,12 +328,18 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
     };
     const bool inv = flag_grad || need_inverse;
     const int want_mode = inv ? 1 : (store_ukk ? 2 : 0);   // bit 0: U rows + alpha; 2: diagonal blocks U_kk only (k_predict)
-    // few large patients: one workgroup per 64-row block and two launches per panel (kernels_cholinv_mc.h)
-    // measured on MI355X (D=24, factorisation ms, multi-CU vs one 8-wave workgroup per patient; scratch/quick_shapes.py):
-    // N=512: 64 patients 0.60 vs 0.84, 128: 0.80 vs 0.89, 192: 1.18 vs 0.93; N=1024: 64: 2.0 vs 4.8, 128: 3.9 vs 4.9,
-    // 200: 6.0 vs 5.1; N=2048: 16: 4.4 vs 32, 64: 11.4 vs 33.5.  The multi-CU time grows linearly with the batch, the
-    // single-workgroup time is flat up to one patient per CU: the crossover sits near 0.6 #CU for every N >= 512.
-    const bool multi_cu = !c->use_v0 && !c->pin_route && (c->force_mc > 0 || (c->force_mc == 0 && nt64 >= 2 && nbatch <= (c->num_cu * 3) / 5));
+    // Few large patients: the multi-CU look-ahead schedule (kernels_cholinv_la.h) instead of one workgroup per patient.
+    // Measured on MI355X, round 4 (scratch/route_sweep.py -> profiles/r04_route_table.txt; factorisation ms per call, nlml + gradient,
+    // LA = look-ahead schedule, 44 / 84 = k_cholinv<4,4> / <8,4>; the same table at D = 2 and D = 24):
+    //   N=128: 44 wins at every batch size (0.069 vs LA 0.073 at 8 entries, 0.081 vs 0.112 at 256)
+    //   N=256: LA <= 96 entries (0.127 / 0.168 vs 44: 0.168 / 0.182 at 8 / 96), 44 from 128 on (0.185 vs LA 0.197)
+    //   N=384: LA <= 128 (0.390 vs 84: 0.395), 84 from 160 on (0.412 vs LA 0.473)
+    //   N=512: LA <= 96 (0.560 vs 0.683), tie at 128 (0.709 / 0.705), 84 from 160 on (0.712 vs 0.885)
+    //   N=768 / 1024: LA <= 128 (1.78 vs 1.86; 3.46 vs 3.69), 84 from 160 on (1.91 vs 2.19; 3.74 vs 4.34)
+    // The LA time grows linearly with the batch, the single-workgroup time is flat up to one patient per CU.  Rule: never for two
+    // blocks; up to 7/16 #CU entries (112) for three or four blocks; up to 9/16 #CU (144) from five blocks on.
+    const int la_max_batch = nt64 <= 2 ? 0 : (nt64 <= 4 ? (c->num_cu * 7) / 16 : (c->num_cu * 9) / 16);
+    const bool multi_cu = !c->use_v0 && !c->pin_route && (c->force_mc > 0 || (c->force_mc == 0 && nbatch <= la_max_batch));
 #ifdef MEDGP_LEGACY_AB
     if (c->use_v0) {
         launch_assemble();
