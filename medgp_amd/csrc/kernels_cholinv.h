@@ -421,18 +421,23 @@ __device__ __forceinline__ void trail_tile(ld_t *D, int s2, int u, int t, int li
 #else
 #define DFW_SETFAIL() do { if (lane == 0) *fail = 1; } while (0)
 #endif
+// x00 != nullptr (a compile-time property of the call site): wave 0 of the CALLER has already run diag16 on tile (0,0) -- L(0,0) is in
+// place in D, dv[0..16) is set, a bad pivot is flagged -- and left the tile's inverse in the 16 x 16 scratch tile x00 (row stride
+// CI_S) because X's own tile was still being read by the other waves; it is copied into place here.  (The look-ahead chain starts
+// the first tile's factorisation as soon as its own 16 rows of the rank-64 update are done, kernels_cholinv_la.h step (5).)
 #ifdef LA_FSTAMPS   // diagnostic build: cumulative s_memtime stamps of wave 0 inside the four-wave factor (scratch/la_stamps.py)
 #define FST(i) do { if (fst && wave == 0 && lane == 0) fst[i] = __builtin_amdgcn_s_memtime() - fst_t0; } while (0)
-__device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t *fail, ld_t *logdet, int wave, int lane, unsigned long long *fst = nullptr) {
+__device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t *fail, ld_t *logdet, int wave, int lane, const ld_t *x00 = nullptr, unsigned long long *fst = nullptr) {
     const unsigned long long fst_t0 = __builtin_amdgcn_s_memtime();
 #else
 #define FST(i) do {} while (0)
-__device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t *fail, ld_t *logdet, int wave, int lane) {
+__device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t *fail, ld_t *logdet, int wave, int lane, const ld_t *x00 = nullptr) {
 #endif
     const int li = lane & 15, g = lane >> 4;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
     if (wave == 0) {
-        if (!diag16(TD(0, 0), TX(0, 0), dv, dv + 64, lane)) { DFW_SETFAIL(); }
+        if (x00) tile_st(TX(0, 0), tile_ld(x00, li, g), li, g);
+        else if (!diag16(TD(0, 0), TX(0, 0), dv, dv + 64, lane)) { DFW_SETFAIL(); }
     }
     FST(0);
     __syncthreads();

@@ -39,6 +39,9 @@ __host__ __device__ inline int la_slice_len(int k) { return k < 32 ? LA_SLICE : 
 #ifndef LA_F_LATE
 #define LA_F_LATE 0       // 1: F tasks request X_k / the pre-solve copy after their partial sums instead of up front
 #endif
+#ifndef LA_D_EARLY
+#define LA_D_EARLY 1      // 1: the chain's wave 0 factors the first 16 x 16 tile of the next diagonal block beside the other waves' rank-64 update (step (5))
+#endif
 #ifndef LA_NSUM
 #define LA_NSUM 3         // partial-sum slabs an F task requests per memory round trip
 #endif
@@ -77,6 +80,7 @@ struct LaSmem {
     };
     double Ls[64][LA_S];                 // L[C_k+1, C_k] (B operand of the newest rank-64 term), later X_k+1 (factor output)
     alignas(16) double dv[64 + 128];                 // diag(L_kk) + the panel scratch of diag16
+    double X00[16][CI_S];                // inverse of the first 16 x 16 tile while Ls is still an operand (early start of the factor, step (5))
     double logdet;
     int fail;
 };
@@ -487,6 +491,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     // ---- (2) X_k -> LDS (Bs is dead: la_gemm ends with a barrier)
 #pragma unroll
     for (int e = 0; e < 8; e++) { const int idx = 2 * (tid + LA_THREADS * e); *(v2d *)&sm.Xs[idx >> 6][idx & 63] = xreg[e]; }
+    if (is_D && tid == 0) { sm.fail = 0; sm.logdet = 0.0; }   // (before the first barrier: wave 0 starts factoring ahead of the others, step (5))
     __syncthreads();
     // ---- (3) L[C_k+1, C_k] = P_k+1,k X_k^T for the wave's 16 rows of block k+1 -> LDS (and, D only, to memory)
     v4d o[4];
@@ -519,6 +524,43 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] += dsv[e];
     }
+#if !LA_D_EARLY
+    const bool d_split = false;
+#else
+    const bool d_split = is_D;
+#endif
+    if (d_split) {
+        // D role: the next diagonal block is symmetric and only its lower tiles (column tile <= the wave's row tile) are ever read,
+        // and the factorisation of its FIRST 16 x 16 tile needs nothing but the 16 rows wave 0 owns.  Wave 0 therefore computes that
+        // one tile (16 MFMAs) and starts diag16 on it at once, while waves 1-3 run their rows of the rank-64 update (2, 3, 4 tiles):
+        // the serial chain of the block's 64 pivots begins ~6 k cycles earlier than behind the full update and a barrier (round 4,
+        // profiles/r04_la_phase_stamps.txt).  Every tile receives the same MFMAs in the same order as before: same bits.
+        // X_k in Xs is dead (every wave passed the barrier behind its trsm), so the tiles of D_k+1 go there directly; the inverse
+        // of the first tile goes to sm.X00 because the other waves still read Ls as the B operand of their updates.
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+            if (cb <= w) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(o[ct][r], sm.Ls[16 * cb + li][16 * ct + 4 * r + g], acc[cb], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) sm.Xs[16 * w + 4 * r + g][16 * cb + li] = -acc[cb][r];
+            }
+        }
+        if (w == 0) {
+            __builtin_amdgcn_wave_barrier();
+            if (!diag16((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.X00[0][0], (ld_t *)sm.dv, (ld_t *)sm.dv + 64, lane)) { if (lane == 0) sm.fail = 1; }
+        } else {
+            // final L[C_k+1, C_k] to memory from the LDS tile (complete since the barrier above; 16-byte accesses, whole lines): by the
+            // three waves that would otherwise wait for wave 0 at the next barrier
+            for (int e = tid - 64; e < 64 * 32; e += LA_THREADS - 64) {
+                const int rr = e >> 5, cc = 2 * (e & 31);
+                *(v2d *)&Lb[(size_t)(c1 + rr) * ld + c0 + cc] = *(const v2d *)&sm.Ls[rr][cc];
+            }
+        }
+    } else {
 #pragma unroll
     for (int ct = 0; ct < 4; ct++)
 #pragma unroll
@@ -528,6 +570,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
             for (int cb = 0; cb < 4; cb++)
                 acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sm.Ls[16 * cb + li][16 * ct + 4 * r + g], acc[cb], 0, 0, 0);
         }
+    }
     if (!is_D) {
         // pre-solve block of panel k+1 (value = -acc), stored in place
 #pragma unroll
@@ -579,20 +622,30 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     LA_TD(5);
     // ---- (6) D: factor the next diagonal block
     __syncthreads();   // every wave is done reading Xs / Ls
+#if !LA_D_EARLY
     for (int e = tid; e < 64 * 32; e += LA_THREADS) {   // final L[C_k+1, C_k]: 16-byte accesses, whole lines
         const int rr = e >> 5, cc = 2 * (e & 31);
         *(v2d *)&Lb[(size_t)(c1 + rr) * ld + c0 + cc] = *(const v2d *)&sm.Ls[rr][cc];
     }
-    if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
+#endif
+#if LA_D_EARLY
+    // (the tiles of D_k+1 are in Xs already, the first one factored, L[C_k+1, C_k] stored: step (5); the barrier above covers all of it)
+#ifdef LA_FSTAMPS
+    diag_factor_wg((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.Ls[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, w, lane, (const ld_t *)&sm.X00[0][0], (unsigned long long *)L.slab + 2048 + 16 * k);
+#else
+    diag_factor_wg((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.Ls[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, w, lane, (const ld_t *)&sm.X00[0][0]);
+#endif
+#else
 #pragma unroll
     for (int ct = 0; ct < 4; ct++)
 #pragma unroll
         for (int r = 0; r < 4; r++) sm.Xs[16 * w + 4 * r + g][16 * ct + li] = -acc[ct][r];
     __syncthreads();
 #ifdef LA_FSTAMPS
-    diag_factor_wg((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.Ls[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, w, lane, (unsigned long long *)L.slab + 2048 + 16 * k);
+    diag_factor_wg((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.Ls[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, w, lane, nullptr, (unsigned long long *)L.slab + 2048 + 16 * k);
 #else
     diag_factor_wg((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.Ls[0][0], (ld_t *)sm.dv, (li_t *)&sm.fail, (ld_t *)&sm.logdet, w, lane);
+#endif
 #endif
     __syncthreads();
     LA_TD(6);
