@@ -56,27 +56,6 @@ __device__ __forceinline__ v2d ci_bload(__amdgpu_buffer_rsrc_t rs, int voff, int
 //  block; with fixed-body phases and scalar-pinned tables it no longer does -- scratch/hotloop_spills.sh checks the ISA.)
 #define STAMP(idx) do {} while (0)
 #endif
-#ifndef CI_SLAB_INIT
-#define CI_SLAB_INIT 1
-#endif
-// A/B switches (default off): wave priority of the VALU / LDS phases around the MFMA loop (-DCI_EXP_PRIO_INIT=n, -DCI_EXP_PRIO_TRSM=n)
-#ifdef CI_EXP_PRIO_INIT
-#define CI_PRIO_INIT_ON() __builtin_amdgcn_s_setprio(CI_EXP_PRIO_INIT)
-#define CI_PRIO_INIT_OFF() __builtin_amdgcn_s_setprio(0)
-#else
-#define CI_PRIO_INIT_ON() do {} while (0)
-#define CI_PRIO_INIT_OFF() do {} while (0)
-#endif
-#ifdef CI_EXP_PRIO_TRSM
-#define CI_PRIO_TRSM_ON() __builtin_amdgcn_s_setprio(CI_EXP_PRIO_TRSM)
-#define CI_PRIO_TRSM_OFF() __builtin_amdgcn_s_setprio(0)
-#else
-#define CI_PRIO_TRSM_ON() do {} while (0)
-#define CI_PRIO_TRSM_OFF() do {} while (0)
-#endif
-#ifndef CI_SLAB_STORE
-#define CI_SLAB_STORE 1
-#endif
 #define CI_ST 18          // row stride (doubles) of a wave's transposition slab: 144 B keeps 16-byte alignment
 
 template <int NW, int UPW>
@@ -111,24 +90,8 @@ static_assert(sizeof(CholInvSmem<4, 4>) <= 80 * 1024, "two 4-wave workgroups per
 // Every "-x" that used to feed an MFMA (48 v_xor per pass in the panel solve, 64 in the panel init, the trailing updates of the
 // diagonal factor) is gone: next to the co-resident workgroup's MFMA stream each VALU instruction waits for the pipe.
 #define MFMA_NEGA 1
-// Diagnostic build only (-DCI_EXP_FP32_EMUL, results meaningless, never shipped): TIMING emulation of an fp32 twin of this kernel --
-// the chunk-loop and panel-solve MFMAs become v_mfma_f32_16x16x4_f32 on the low words (same shape, half the cycles), every second
-// history-operand request and half of the staged operand are dropped, half of the panel stores are skipped: the matrix pipe time and
-// the bytes of an fp32 kernel, with this kernel's serial phases and fp64 diagonal factor left as they are.
-#ifdef CI_EXP_FP32_EMUL
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v4d mfma_emul32(double a, double b, v4d c) {
-    union { v4d d; v4f f[2]; } u;
-    u.d = c;
-    u.f[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(__double2loint(a)), __int_as_float(__double2loint(b)), u.f[0], 0, 0, 0);
-    return u.d;
-}
-#define CI_MFMA_LOOP(a, b, c) mfma_emul32((a), (b), (c))
-#define CI_MFMA_TRSM(a, b, c) mfma_emul32((a), (b), (c))
-#else
 #define CI_MFMA_LOOP(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, MFMA_NEGA)
 #define CI_MFMA_TRSM(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-#endif
 
 __device__ inline double readlane_d(double v, int srclane) {   // srclane must be wave-uniform
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -416,11 +379,7 @@ __device__ __forceinline__ void trail_tile(ld_t *D, int s2, int u, int t, int li
 }
 // (inlined into its callers: as an out-of-line function it claimed 248 VGPRs + 32 AGPRs for callee-saved traffic, and a kernel is
 //  allocated the maximum over its call graph -- k_la_step lost its second workgroup per CU to a callee it runs in one role)
-#ifdef LA_EXP_NOINV
-#define DFW_SETFAIL() do {} while (0)   // the garbage this diagnostic build produces must not end the factor early
-#else
 #define DFW_SETFAIL() do { if (lane == 0) *fail = 1; } while (0)
-#endif
 // x00 != nullptr (a compile-time property of the call site): wave 0 of the CALLER has already run diag16 on tile (0,0) -- L(0,0) is in
 // place in D, dv[0..16) is set, a bad pivot is flagged -- and left the tile's inverse in the 16 x 16 scratch tile x00 (row stride
 // CI_S) because X's own tile was still being read by the other waves; it is copied into place here.  (The look-ahead chain starts
@@ -469,19 +428,15 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
                     e++;
                 }
             // finished inverse row t (t >= 1): tiles X(t, 0..t-1)
-#ifndef LA_EXP_NOINV   // (diagnostic build, results meaningless: prices the off-diagonal tiles of the inverse)
             if (t >= 1 && wave - 1 < t) inv_row_tiles(D, X, t, wave - 1, li, g);
-#endif
         }
         __syncthreads();
         if (*fail) return;
     }
     FST(10);
     // ---- tail: inverse rows 3 (and row 2 was done in phase B(2))
-#ifndef LA_EXP_NOINV
     if (wave < 3) inv_row_tiles(D, X, 3, wave, li, g);
     else
-#endif
     if (wave == 3) {
 #pragma unroll
         for (int t = 1; t < 4; t++)
@@ -504,15 +459,6 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
 // short-history wave wait for a long-history one (whole-block ownership: 75 % balance at N = 512), and chunks before the
 // pass's first non-zero history column are skipped for the whole workgroup.  The active units of a wave at chunk c
 // are a prefix of its slots, so the chunk body is instantiated per prefix length.
-// Diagnostic build only (-DCI_EXP_ALIAS=n): history operands are read from batch entry b % n and scaled by zero, so the
-// kernel keeps its instruction stream but its history traffic becomes cache resident (results are wrong by design).
-#ifdef CI_EXP_ALIAS
-#define CI_EXP_OFF exp_off
-#define CI_EXP_SCALE(x) ((x) * exp_zero)
-#else
-#define CI_EXP_OFF 0
-#define CI_EXP_SCALE(x) (x)
-#endif
 // One phase of the chunk loop: chunks [lo, hi) during which exactly the first NA units of this wave are active.
 // One phase of the chunk loop: chunks [lo, hi) during which exactly the first NA units of this wave are active.
 // Software pipeline (CI_KC = 16 columns per chunk = two 8-column halves):
@@ -528,11 +474,7 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
 #define CI_NACT(x) (((x) >= pb[0]) + ((x) >= pb[1]) + ((x) >= pb[2]) + ((x) >= pb[3]))
 // buffer_load with the matrix descriptor in SGPRs, a 32-bit lane offset and a scalar (unit row + chunk) offset: no 64-bit
 // per-lane address arithmetic and no address registers held across the loop (T8 of the guide)
-#ifdef CI_EXP_FP32_EMUL
-#define CI_HLOAD(u, h, cc) { if ((h) == 0) hc[u][h] = ci_bload(rsu[u], voffh + 64 * (h), urow[u] + (cc) * (CI_KC * 8)); }
-#else
 #define CI_HLOAD(u, h, cc) hc[u][h] = ci_bload(rsu[u], voffh + 64 * (h), urow[u] + (cc) * (CI_KC * 8))
-#endif
 // The loop body is straight-line code (the waitcnt pass counts outstanding loads exactly only without branches around
 // them): the requests for chunk c + 1 are unconditional, in the last chunk they re-read that chunk (index clamped) and
 // the result is dropped.  Units that become active at a phase boundary are requested by CI_PHASE_ENTER between the loops.
@@ -541,23 +483,8 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
         _Pragma("unroll") for (int u = NA0; u < UPW; u++)                                                          \
             if (u < (NA1)) { CI_HLOAD(u, 0, (cc)); CI_HLOAD(u, 1, (cc)); }                                         \
     }
-// Staging of the shared operand: chunk c + 1 is stored into LDS at the end of iteration c.  CI_STAGE_DEEP=1 requests it TWO
-// iterations ahead (a second register set of SPT doubles) instead of at the top of the iteration that stores it.
-#ifndef CI_STAGE_DEEP
-#define CI_STAGE_DEEP 0
-#endif
-#if CI_STAGE_DEEP
-#define CI_STAGE_LOAD(c, cn) { const int cn2 = ((c) + 2 < nch) ? (c) + 2 : nch - 1;                                 \
-        _Pragma("unroll") for (int e = 0; e < SPT; e++) bnn[e] = Bsrc[cn2 * CI_KC + e]; }
-#define CI_STAGE_ROTATE() { _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = bnn[e]; }
-#else
-#ifdef CI_EXP_FP32_EMUL
-#define CI_STAGE_LOAD(c, cn) { _Pragma("unroll") for (int e = 0; e < SPT / 2; e++) bnext[e] = Bsrc[(cn) * CI_KC + e]; }
-#else
+// Staging of the shared operand: chunk c + 1 is requested at the top of iteration c and stored into LDS at its end.
 #define CI_STAGE_LOAD(c, cn) { _Pragma("unroll") for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[(cn) * CI_KC + e]; }
-#endif
-#define CI_STAGE_ROTATE() {}
-#endif
 #define CI_CHUNK_PHASE(NA, lo, hi)                                                                                 \
     for (int c = (lo); c < (hi); c++) {                                                                            \
         const int buf = c & 1;                                                                                     \
@@ -593,7 +520,6 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
         if (c + 1 < nch) {                                                                                         \
             _Pragma("unroll") for (int e = 0; e < SPT; e++) sm.Bs[buf ^ 1][srow][scol + e] = bnext[e];             \
         }                                                                                                          \
-        CI_STAGE_ROTATE()                                                                                          \
         STAMP(6); /* staging store (waits for this iteration's B loads) */                                         \
         __syncthreads();                                                                                           \
         STAMP(7); /* chunk barrier wait */                                                                         \
@@ -636,10 +562,6 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
     const int srow8 = lane_o >> 3, spc = lane_o & 7;     \
     double (*S)[CI_ST] = sm.St[hwave]
 
-#ifdef CI_EXP_ALIAS
-    const long exp_off = ((long)(b % CI_EXP_ALIAS) - (long)b) * ld * ld;
-    const double exp_zero = (L.ldn < 0) ? 1.0 : 0.0;   // opaque zero
-#endif
     if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
     __syncthreads();
 #ifdef MEDGP_STAMPS
@@ -690,19 +612,13 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
             // block read slot 0's and discard it): with a branch per unit hipcc spilled four accumulator tiles inside the
             // MFMA loop (2.2 ms); branch-free the loop is spill free and the kernel gains 3 % over 8-byte loads of the
             // transposed layout (1.69 -> 1.64 ms at 512 x N=512).
-#if CI_SLAB_INIT
             v4d acc[4][UPW];
-            CI_PRIO_INIT_ON();
             {
                 CI_SLAB_LANE();
                 bool ldu[UPW], anyld = false;
 #pragma unroll
                 for (int u = 0; u < UPW; u++) { ldu[u] = act[u] && isM[u]; anyld = anyld || ldu[u]; }
-#ifdef CI_EXP_NOINIT   // diagnostic build (results meaningless): prices the panel init (K-block loads + LDS transposition)
-                if (false) {
-#else
                 if (anyld) {   // branch-free inside: units without a K block read the block of slot 0 and discard it
-#endif
                     // all 64 columns are requested at once (the registers the accumulators will occupy are free here): one
                     // memory round trip per pass instead of one per 32-column half
                     v2d kin[4][2 * UPW];
@@ -740,20 +656,6 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                         for (int u = 0; u < UPW; u++) acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
                 }
             }
-#else
-            v4d acc[4][UPW];
-#pragma unroll
-            for (int ct = 0; ct < 4; ct++)
-#pragma unroll
-                for (int u = 0; u < UPW; u++) {
-                    acc[ct][u] = (v4d){0.0, 0.0, 0.0, 0.0};
-                    if (act[u] && isM[u]) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) acc[ct][u][r] = ub[u][(size_t)li * ld + c0 + 16 * ct + 4 * r + g];
-                    }
-                }
-#endif
-            CI_PRIO_INIT_OFF();
             STAMP(0);   // panel init
             double zsum = 0.0;
             // ---- GEMM over the history, B chunk (L[C_k rows]) staged through LDS, double buffered
@@ -763,21 +665,11 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 const int srow = (tid * SPT) / CI_KC, scol = (tid * SPT) % CI_KC;
                 const gd_t *Bsrc = Lb + (size_t)(c0 + srow) * ld + scol;
                 double bnext[SPT];
-#if CI_STAGE_DEEP
-                double bnn[SPT];
-#endif
 #pragma unroll
                 for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[cstart * CI_KC + e];
                 __syncthreads();   // every wave is done with its init slab (St aliases Bs)
 #pragma unroll
                 for (int e = 0; e < SPT; e++) sm.Bs[cstart & 1][srow][scol + e] = bnext[e];
-#if CI_STAGE_DEEP
-                {   // chunk cstart + 1 is on its way before the loop starts
-                    const int c1 = (cstart + 1 < nch) ? cstart + 1 : nch - 1;
-#pragma unroll
-                    for (int e = 0; e < SPT; e++) bnext[e] = Bsrc[c1 * CI_KC + e];
-                }
-#endif
                 __syncthreads();
                 // The history operand of a chunk is loaded and consumed in the same iteration: NO software prefetch.
                 // Measured: hipcc turns every use of a prefetched register into `s_waitcnt vmcnt(0)`, so a register
@@ -804,15 +696,6 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 __syncthreads();   // init slabs done before Dk (same LDS) is written below
             }
             STAMP(1);
-#ifdef CI_EXP_AHEAD_EMUL   // diagnostic build (results meaningless): the factor runs on wave 0 AFTER the chunk loop of pass 1, beside
-                           // the other waves' panel solve -- prices a look-ahead factor that joins the chunk barriers
-            if (pass == 1 && wave == 0) {
-                // a valid (identity) input: the factor's time does not depend on the data, but a bad pivot would end it early
-                for (int cc = 0; cc < 64; cc++) sm.Dk[lane][cc] = (cc == lane) ? 1.0 : 0.0;
-                __builtin_amdgcn_wave_barrier();
-                diag_factor_wave((ld_t *)&sm.Dk[0][0], (ld_t *)&sm.Xk[0][0], (ld_t *)sm.rhs, (li_t *)&sm.red[8], (ld_t *)&sm.red[0], lane);
-            }
-#endif
             if (pass == 0) {
                 // diagonal block = slot 0 of group 0: every wave of the group holds 16 of its rows
                 if (wg == 0) {
@@ -834,16 +717,10 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                     for (int w2 = 0; w2 < NW; w2++) zacc += sm.zpart[w2][lane];
                 }
-#if defined(CI_EXP_FP32_EMUL) || defined(CI_EXP_NOINIT) || defined(CI_EXP_NOTRSM)   // diagnostic builds with garbage products: give the (fp64) factor a valid block so that it runs its full course
-                if (wave == 0) { for (int cc = 0; cc < 64; cc++) sm.Dk[lane][cc] = (cc == lane) ? 1.0 : 0.0; }
-                __builtin_amdgcn_wave_barrier();
-#endif
-#if !defined(CI_EXP_NOFACTOR) && !defined(CI_EXP_AHEAD_EMUL)   // diagnostic builds: factor skipped (results meaningless), prices the factor phase
                 // (k_cholinv<8,2> with the factor inlined and 128 VGPRs -- two 8-wave workgroups per CU, four waves per SIMD --
                 //  was tried: alone it matches <8,4> (0.81 ms at 256 patients), but at 128 VGPRs hipcc spills inside the chunk
                 //  loops and 376 scratch operations into the factor: 2.30 ms at 512 patients against 1.38 ms for <4,4>)
                 if (wave == 0) diag_factor_wave((ld_t *)&sm.Dk[0][0], (ld_t *)&sm.Xk[0][0], (ld_t *)sm.rhs, (li_t *)&sm.fail, (ld_t *)&sm.logdet, lane);
-#endif
                 __syncthreads();   // factor done: Dk = L_kk, Xk = L_kk^-1 (or fail)
                 STAMP(3);   // diagonal factor
                 if (sm.fail) return false;
@@ -893,20 +770,11 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             STAMP(3);   // L_kk / U_kk stores (folded into diag)
-            CI_PRIO_TRSM_ON();
             // ---- triangular solve as GEMM: out^T[ct] = sum_{ct' <= ct} Xk[ct, ct'] acc^T[ct'] on all four units (an
             //      inactive or diagonal unit computes on zeros / unused values: 40 MFMAs, never stored); each 16-column
             //      slab goes through the wave's LDS slab and leaves as whole 128-byte lines
-#ifdef CI_EXP_AHEAD_EMUL
-            if (!(pass == 1 && wave == 0))   // the emulated look-ahead wave owns no units in this pass: no panel solve, no stores
-#endif
-#ifdef CI_EXP_NOTRSM   // diagnostic build (results meaningless): prices the panel solve + stores
-            if (L.ldn < 0)
-#endif
             {
-#if CI_SLAB_STORE
                 CI_SLAB_LANE();
-#endif
                 bool st[UPW];
                 double pal[UPW];
 #pragma unroll
@@ -924,7 +792,6 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                             for (int u = 0; u < UPW; u++) o[u] = CI_MFMA_TRSM(a, acc[cp][u][r], o[u]);
                         }
-#if CI_SLAB_STORE
 #pragma unroll
                     for (int u = 0; u < UPW; u++) {
 #pragma unroll
@@ -938,33 +805,12 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 #pragma unroll
                     for (int i = 0; i < 2 * UPW; i++) {
                         const int u = i >> 1;
-#ifdef CI_EXP_FP32_EMUL
-                        if (st[u] && !(ct & 1)) {
-#else
                         if (st[u]) {
-#endif
                             gd_t *Out = (isM[u] ? Lb : Ub) + (size_t)(rowb[u] + 8 * (i & 1) + srow8) * ld + c0 + 16 * ct + 2 * spc;
-#ifdef CI_EXP_NOSTORE
-                            if (L.ldn < 0)   // diagnostic: never true
-#endif
                             *(gv2d_t *)Out = *(const v2d *)&S[8 * i + srow8][2 * spc];
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
-#else
-#pragma unroll
-                    for (int u = 0; u < UPW; u++) {
-                        if (st[u]) {
-                            gd_t *Out = (isM[u] ? Lb : Ub) + (size_t)(rowb[u] + li) * ld + c0 + 16 * ct + g;
-#pragma unroll
-                            for (int r = 0; r < 4; r++) Out[4 * r] = o[u][r];
-                            if (!isM[u]) {
-#pragma unroll
-                                for (int r = 0; r < 4; r++) pal[u] += o[u][r] * sm.zk[16 * ct + 4 * r + g];
-                            }
-                        }
-                    }
-#endif
                 }
 #pragma unroll
                 for (int u = 0; u < UPW; u++) {
@@ -976,7 +822,6 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                     }
                 }
             }
-            CI_PRIO_TRSM_OFF();
             STAMP(5);   // panel solve + stores
             // Visibility of this pass's stores: columns C_k are first read in step k + 1, at chunk 4k - 1 (B staging) or
             // later, i.e. after >= 3 chunk barriers (each a full __syncthreads with vmcnt(0)) when k >= 1 -- no need to
@@ -1017,12 +862,6 @@ __global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int wa
     if constexpr (SEL == 2) { if (L.status[b] != -2) return; }
     else { if (L.status[b] < 0) return; }
     if constexpr (SEL == 1) { if (L.pn[L.bslot[b]] > 64) return; }
-#ifdef CI_EXP_STAGGER
-    // experiment: the second resident workgroup of a CU starts half a step late (anti-phase GEMM / serial phases)
-    if (NW == 4 && ((CI_EXP_STAGGER_MODE == 0 && b >= (int)gridDim.x / 2) || (CI_EXP_STAGGER_MODE == 1 && (b & 1)))) {
-        for (int it = 0; it < CI_EXP_STAGGER; it++) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     // loaded values the whole workgroup agrees on: pin them to scalar registers, otherwise every quantity derived from
     // n (block counts, slot tables, row bases) lives in VGPRs across the MFMA loop and its branches run on exec masks
     const int slot = __builtin_amdgcn_readfirstlane(L.bslot[b]);

@@ -649,9 +649,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
 #endif
     __syncthreads();
     LA_TD(6);
-#ifndef LA_EXP_NOINV
     if (sm.fail) return 1;
-#endif
     double *Xn = A.xk2 + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096;
     // (two columns per lane and store: 16-byte accesses, 8 passes instead of 16 on the tail of the chain)
     for (int e = tid; e < 64 * 32; e += LA_THREADS) {

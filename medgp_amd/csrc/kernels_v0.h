@@ -1,8 +1,9 @@
-// kernels_v0.h -- the first correct HIP statement of the stages (no MFMA, simple tiling).  Product code: the generic route for
-// Q > 8 mixture components (k_assemble_v0, k_lauum_v0, k_gradbins_v0 -- the tuned kernels are instantiated for Q <= 8), checked
-// against the same oracle as the tuned kernels (tests/test_parity_gpu.py, Q = 9).  The first-generation dense kernels
-// (k_potrf_v0, k_trtri_v0: Cholesky + forward solve, triangular inverse) are A/B code and only compiled with
-// -DMEDGP_LEGACY_AB (make LEGACY=1 builds such a library; MEDGP_V0=1 then selects them at run time).
+// kernels_v0.h -- the generic (non-templated, no MFMA in the pair loops) route for Q > 8 mixture components: k_assemble_v0,
+// k_lauum_v0, k_gradbins_v0 (the tuned kernels are instantiated for Q <= 8; Q is a free configuration key of the reference,
+// ref: kernel/c_kernel_LMC_SM.cpp:51-70).  Checked against the same oracle as the tuned kernels (tests/test_parity_gpu.py, Q = 9);
+// MEDGP_V0=1 selects them for any Q (A/B parity).  The dense stages always run on k_cholinv / the look-ahead schedule.  (The
+// first-generation dense kernels k_potrf_v0 / k_trtri_v0 and the first multi-CU schedule k_ci_* left the tree in round 4: git
+// history keeps them.)
 #pragma once
 #include "kernels_core.h"
 
@@ -38,195 +39,6 @@ __global__ void __launch_bounds__(256) k_assemble_v0(MedgpDev L) {
 
 // whole-matrix re-assembly by one workgroup with `count` extra noise additions (jitter path)
 //   ref: c_inference_exact.cpp:99-108
-#ifdef MEDGP_LEGACY_AB
-// ------------------------------------------------------------------------------------------
-// stage 2: Cholesky (lower, in place) + forward solve z = L^-1 y + log-det + quad, with the
-// reference's jitter-retry loop.  Right-looking, 16-wide panels, one workgroup per problem.
-//   ref: c_inference_exact.cpp:96-125, 146   (LAPACKE_spotrf / spotrs live in MKL)
-// ------------------------------------------------------------------------------------------
-struct PotrfSmem {
-    double Akk[16][17];
-    double Pi[64][17];
-    double Pj[64][17];
-    double zb[16];
-    double red[256];
-    double logdet;
-    int fail;
-};
-
-__device__ bool potrf_wg_v0(double *A, int ld, int np, double *zz, PotrfSmem &sm) {
-    const int tid = threadIdx.x, r = tid >> 4, c = tid & 15;
-    if (tid == 0) { sm.fail = 0; sm.logdet = 0.0; }
-    __syncthreads();
-    for (int k0 = 0; k0 < np; k0 += 16) {
-        sm.Akk[r][c] = A[(size_t)(k0 + r) * ld + k0 + c];
-        __syncthreads();
-        for (int j = 0; j < 16; j++) {
-            if (tid == 0) {
-                double piv = sm.Akk[j][j];
-                if (!(piv > 0.0)) sm.fail = 1;   // LAPACK potf2: ajj <= 0 or NaN
-                else { piv = sqrt(piv); sm.Akk[j][j] = piv; sm.logdet += log(piv); }
-            }
-            __syncthreads();
-            if (sm.fail) return false;
-            if (c == j && r > j) sm.Akk[r][j] /= sm.Akk[j][j];
-            __syncthreads();
-            if (c > j && r >= c) sm.Akk[r][c] -= sm.Akk[r][j] * sm.Akk[c][j];
-            __syncthreads();
-        }
-        if (r >= c) A[(size_t)(k0 + r) * ld + k0 + c] = sm.Akk[r][c];
-        // z block: L_kk z_k = y_k (already updated by previous panels)
-        if (tid == 0) {
-            for (int rr = 0; rr < 16; rr++) {
-                double s = zz[k0 + rr];
-                for (int cc = 0; cc < rr; cc++) s -= sm.Akk[rr][cc] * sm.zb[cc];
-                s /= sm.Akk[rr][rr];
-                sm.zb[rr] = s;
-                zz[k0 + rr] = s;
-            }
-        }
-        __syncthreads();
-        // panel: rows below solve x L_kk^T = a; update z
-        for (int i = k0 + 16 + tid; i < np; i += blockDim.x) {
-            double x[16];
-            double *ai = A + (size_t)i * ld + k0;
-            double zacc = 0.0;
-#pragma unroll
-            for (int cc = 0; cc < 16; cc++) x[cc] = ai[cc];
-#pragma unroll
-            for (int cc = 0; cc < 16; cc++) {
-                double s = x[cc];
-#pragma unroll
-                for (int c2 = 0; c2 < cc; c2++) s -= x[c2] * sm.Akk[cc][c2];
-                s /= sm.Akk[cc][cc];
-                x[cc] = s;
-                zacc += s * sm.zb[cc];
-            }
-#pragma unroll
-            for (int cc = 0; cc < 16; cc++) ai[cc] = x[cc];
-            zz[i] -= zacc;
-        }
-        __syncthreads();
-        // trailing update, 64x64 tiles of rows/cols >= k0+16
-        const int m0 = k0 + 16, mt = (np - m0 + 63) / 64;
-        for (int ti = 0; ti < mt; ti++)
-            for (int tj = 0; tj <= ti; tj++) {
-                const int I0 = m0 + ti * 64, J0 = m0 + tj * 64;
-                {
-                    int rr = tid >> 2, c4 = (tid & 3) * 4;
-                    int gi = I0 + rr, gj = J0 + rr;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        sm.Pi[rr][c4 + u] = (gi < np) ? A[(size_t)gi * ld + k0 + c4 + u] : 0.0;
-                        sm.Pj[rr][c4 + u] = (gj < np) ? A[(size_t)gj * ld + k0 + c4 + u] : 0.0;
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int a = 0; a < 4; a++)
-#pragma unroll
-                    for (int bb = 0; bb < 4; bb++) {
-                        int li = r + 16 * a, lj = c + 16 * bb;
-                        int i = I0 + li, j = J0 + lj;
-                        if (i < np && j <= i) {
-                            double s = 0.0;
-#pragma unroll
-                            for (int cc = 0; cc < 16; cc++) s += sm.Pi[li][cc] * sm.Pj[lj][cc];
-                            A[(size_t)i * ld + j] -= s;
-                        }
-                    }
-                __syncthreads();
-            }
-    }
-    return true;
-}
-
-__global__ void __launch_bounds__(256) k_potrf_v0(MedgpDev L) {
-    __shared__ PotrfSmem sm;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (L.status[b] < 0) return;
-    const int slot = L.bslot[b], n = L.pn[slot], np = medgp_roundup(n, 16), ld = L.ldn;
-    double *A = L.Kmat + (size_t)b * ld * ld;
-    double *zz = L.z + (size_t)b * ld;
-    const double *y = L.py + (size_t)slot * ld;
-    int count = 0;
-    while (true) {
-        for (int i = tid; i < ld; i += blockDim.x) zz[i] = (i < n) ? y[i] : 0.0;
-        __syncthreads();
-        if (potrf_wg_v0(A, ld, np, zz, sm)) break;
-        __syncthreads();
-        if (count >= 10) {   // ref: c_inference_exact.cpp:99,109-111
-            if (tid == 0) L.status[b] = -1;
-            return;
-        }
-        count++;
-        reassemble_wg(L, b, slot, n, np, count);
-    }
-    // quad = z^T z, deterministic tree
-    double s = 0.0;
-    for (int i = tid; i < np; i += blockDim.x) s += zz[i] * zz[i];
-    sm.red[tid] = s;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) sm.red[tid] += sm.red[tid + off];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        L.status[b] = count;
-        L.scal[b * 4 + 0] = sm.logdet;
-        L.scal[b * 4 + 1] = sm.red[0];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// stage 3 (v0 fallback): L^-1 by forward substitution, one thread per column; alpha = L^-T z.
-//   ref: c_inference_exact.cpp:124-143 (spotrs, strtri)
-// Stored like k_cholinv does: Linv holds U = L^-T (upper, row-major), (L^-1)[i][j] = U[j][i].
-// Rows/cols in [np16, npad64) are identity padding.
-// ------------------------------------------------------------------------------------------
-#define XU(i, j) X[(size_t)(j) * ld + (i)]
-__global__ void __launch_bounds__(256) k_trtri_v0(MedgpDev L) {
-    const int b = blockIdx.x;
-    if (L.status[b] < 0) return;
-    const int slot = L.bslot[b], n = L.pn[slot], np = medgp_roundup(n, 16), npad = medgp_roundup(n, 64), ld = L.ldn;
-    const double *Lm = L.Kmat + (size_t)b * ld * ld;
-    double *X = L.Linv + (size_t)b * ld * ld;
-    const double *zz = L.z + (size_t)b * ld;
-    double *alpha = L.alpha + (size_t)b * ld;
-    const int lane = threadIdx.x & 63;
-    for (int j = threadIdx.x; j < npad; j += blockDim.x) {
-        const int jw = j - lane;   // first column of this wave (uniform)
-        for (int i = (j & ~63); i < j; i++) XU(i, j) = 0.0;   // zero the strictly-lower part of U's diagonal block
-        if (jw >= np) {            // whole wave in the identity padding
-            for (int i = j; i < npad; i++) XU(i, j) = (i == j) ? 1.0 : 0.0;
-            alpha[j] = 0.0;
-            continue;
-        }
-        const bool real = j < np;
-        if (real) XU(j, j) = 1.0 / Lm[(size_t)j * ld + j];
-        for (int i = jw + 1; i < np; i++) {
-            double s = 0.0;
-            const double *li = Lm + (size_t)i * ld;
-            for (int k = jw; k < i; k++) {
-                double xv = (real && k >= j) ? XU(k, j) : 0.0;
-                s += li[k] * xv;
-            }
-            if (real && i > j) XU(i, j) = -s / li[i];
-        }
-        if (real) {
-            for (int i = np; i < npad; i++) XU(i, j) = 0.0;
-            double a = 0.0;
-            for (int i = j; i < np; i++) a += XU(i, j) * zz[i];
-            alpha[j] = a;
-        } else {
-            for (int i = j; i < npad; i++) XU(i, j) = (i == j) ? 1.0 : 0.0;
-            alpha[j] = 0.0;
-        }
-    }
-}
-#undef XU
-
-#endif  // MEDGP_LEGACY_AB
 
 // ------------------------------------------------------------------------------------------
 // stage 4: W = L^-T L^-1 - alpha alpha^T = U U^T - alpha alpha^T, lower 64x64 tiles, written over the (dead) L buffer

@@ -6,7 +6,6 @@
 #include "kernels_core.h"
 #include "kernels_v0.h"
 #include "kernels_cholinv.h"
-#include "kernels_cholinv_mc.h"
 #include "kernels_cholinv_la.h"
 #include "kernels_assemble.h"
 #include "kernels_wgrad.h"
@@ -24,8 +23,8 @@
 
 namespace {
 
-enum KernelId { KID_PREP = 0, KID_ASSEMBLE, KID_POTRF, KID_TRTRI, KID_CHOLINV, KID_CI_PANEL, KID_CI_TRSM, KID_LA_STEP, KID_LA_AUX, KID_LAUUM, KID_GRADBINS, KID_WGRAD, KID_EPILOGUE, KID_PREDICT, KID_COUNT };
-const char *const kKernelNames[KID_COUNT] = {"k_prep", "k_assemble", "k_potrf", "k_trtri", "k_cholinv", "k_ci_panel", "k_ci_trsm", "k_la_step", "k_la_aux", "k_lauum", "k_gradbins", "k_wgrad", "k_epilogue", "k_predict"};
+enum KernelId { KID_PREP = 0, KID_ASSEMBLE, KID_CHOLINV, KID_LA_STEP, KID_LA_AUX, KID_LAUUM, KID_GRADBINS, KID_WGRAD, KID_EPILOGUE, KID_PREDICT, KID_COUNT };
+const char *const kKernelNames[KID_COUNT] = {"k_prep", "k_assemble", "k_cholinv", "k_la_step", "k_la_aux", "k_lauum", "k_gradbins", "k_wgrad", "k_epilogue", "k_predict"};
 
 thread_local std::string g_create_error;   // last medgp_create error of the calling thread
 
@@ -80,7 +79,6 @@ struct medgp_ctx {
     // scratch of the look-ahead multi-CU factorisation (kernels_cholinv_la.h), grown on demand
     double *d_la_part = nullptr, *d_la_small = nullptr;
     size_t la_part_cap = 0, la_small_cap = 0;
-    int mc_old = 0;           // MEDGP_MC_OLD=1: the first multi-CU schedule (two launches per step), kept for A/B runs
     char *h_bounce = nullptr;        // pinned bounce buffer for the large device-to-host exports (factor matrices)
     size_t bounce_cap = 0;
     int *d_one_slot = nullptr;       // single-entry slot table for the caller-order re-factorisation of medgp_get_factor
@@ -92,7 +90,7 @@ struct medgp_ctx {
     // profiling
     bool profiling = false;
     int profile_only = -1;    // >= 0: only launches of this kernel id are bracketed (medgp_profile_enable(ctx, 2 + id))
-    bool use_v0 = false;      // MEDGP_V0=1: baseline kernels (debug / A-B parity)
+    bool use_v0 = false;      // MEDGP_V0=1: the generic (non-templated) pair kernels of the Q > 8 route for any Q (debug / A-B parity)
     int cholinv_nw = 0;       // MEDGP_CHOLINV_NW=44|84 forces the workgroup shape <waves, 16-row units per wave> (0 = auto)
     int la_park = 256;        // MEDGP_LA_PARK=<workgroup id>|0: where the look-ahead schedule parks its sleeping workgroup (0 = off)
     int la_park_maxbatch = 8; // MEDGP_LA_PARK_MAXBATCH: largest batch the parking is used for (measured: 4 x N=2048 -5 %, 16 x N=2048 +2 %)
@@ -340,53 +338,10 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
     // blocks; up to 7/16 #CU entries (112) for three or four blocks; up to 9/16 #CU (144) from five blocks on.
     const int la_max_batch = nt64 <= 2 ? 0 : (nt64 <= 4 ? (c->num_cu * 7) / 16 : (c->num_cu * 9) / 16);
     const bool multi_cu = !c->use_v0 && !c->pin_route && (c->force_mc > 0 || (c->force_mc == 0 && nbatch <= la_max_batch));
-#ifdef MEDGP_LEGACY_AB
-    if (c->use_v0) {
-        launch_assemble();
-        { Launcher l(c, KID_POTRF, stream); hipLaunchKernelGGL(k_potrf_v0, dim3(nbatch), dim3(256), 0, stream, L); }
-        if (want_mode) { Launcher l(c, KID_TRTRI, stream); hipLaunchKernelGGL(k_trtri_v0, dim3(nbatch), dim3(256), 0, stream, L); }
-    } else
-#endif
     if (multi_cu) {
         // which entries the multi-CU schedule factors: more than one 64-block (host mirror of the patient sizes)
         bool any_small = false;
         for (int bb = 0; bb < nbatch; bb++) any_small = any_small || entry_n[bb] <= 64;
-#ifdef MEDGP_LEGACY_AB
-        if (c->mc_old) {
-            // first multi-CU schedule (two launches per step), host-driven retry loop: a failed pivot leaves status -2, the host
-            // bumps the jitter count of the failed problems and re-runs assembly + factorisation of the batch
-            std::vector<int> hst(nbatch), hjit(nbatch, 0), nst(nbatch);
-            for (int attempt = 0;; attempt++) {
-                launch_assemble();
-                for (int k = 0; k < nt64; k++) {
-                    { Launcher l(c, KID_CI_PANEL, stream); hipLaunchKernelGGL(k_ci_panel, dim3(nbatch, nt64), dim3(MC_THREADS), 0, stream, L, k, want_mode); }
-                    if (nt64 > 1) { Launcher l(c, KID_CI_TRSM, stream); hipLaunchKernelGGL(k_ci_trsm, dim3(nt64 - 1, nbatch), dim3(MC_THREADS), 0, stream, L, k, want_mode); }
-                }
-                hipLaunchKernelGGL(k_ci_finish, dim3(nbatch), dim3(256), 0, stream, L);
-                HIPCHK(c, hipMemcpyAsync(hst.data(), L.status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, stream));
-                HIPCHK(c, hipStreamSynchronize(stream));
-                if (attempt < c->dbg_fail) for (int bb = 0; bb < nbatch; bb++) if (hst[bb] >= 0) hst[bb] = -2;
-                bool retry = false, rewrite = false;
-                for (int bb = 0; bb < nbatch; bb++) {
-                    if (hst[bb] == -2) {
-                        if (hjit[bb] >= 10) { nst[bb] = -1; rewrite = true; }
-                        else { hjit[bb]++; nst[bb] = 0; retry = true; }
-                    } else nst[bb] = hst[bb];
-                }
-                if (!retry) {
-                    if (rewrite) HIPCHK(c, hipMemcpyAsync(L.status, nst.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, stream));
-                    if (rewrite) HIPCHK(c, hipStreamSynchronize(stream));
-                    break;
-                }
-                for (int bb = 0; bb < nbatch; bb++) if (nst[bb] > 0) nst[bb] = 0;
-                std::vector<double> zero4(4 * (size_t)nbatch, 0.0);
-                HIPCHK(c, hipMemcpyAsync(L.status, nst.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, stream));
-                HIPCHK(c, hipMemcpyAsync(L.jit, hjit.data(), sizeof(int) * nbatch, hipMemcpyHostToDevice, stream));
-                HIPCHK(c, hipMemcpyAsync(L.scal, zero4.data(), sizeof(double) * 4 * nbatch, hipMemcpyHostToDevice, stream));
-                HIPCHK(c, hipStreamSynchronize(stream));
-            }
-        } else
-#endif
         {
             LaArgs la{};
             { int rc = ensure_la(c, nbatch, nt64, &la); if (rc) return rc; }
@@ -558,10 +513,6 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
         return fail(nullptr, MEDGP_ERR_HIP, "cannot initialise device %d", device);
     }
     c->stream = c->own_stream;
-#ifdef MEDGP_LEGACY_AB   // first-generation kernels: A/B builds only (make LEGACY=1)
-    { const char *e = getenv("MEDGP_V0"); c->use_v0 = e && e[0] == '1'; }
-    { const char *e = getenv("MEDGP_MC_OLD"); c->mc_old = e ? atoi(e) : 0; }
-#endif
     { const char *e = getenv("MEDGP_CHOLINV_NW"); c->cholinv_nw = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_LA_PARK"); if (e) c->la_park = atoi(e); }
     { const char *e = getenv("MEDGP_LA_PARK_MAXBATCH"); if (e) c->la_park_maxbatch = atoi(e); }

@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 
 import medgp_amd
 from medgp_amd import capi, synth
+from oracle import oracle as O
 
 
 def _ctx(P=12, D=3, N=70, Q=3, R=2, max_batch=None):
@@ -206,3 +207,55 @@ def test_profile_only_one_kernel_brackets_just_that_kernel():
     full = {k for k, v in ctx.profile_read().items() if v[1] > 0}
     ctx.profile_enable(False)
     assert {"k_prep", "k_assemble", "k_wgrad", "k_epilogue"} <= full
+
+
+def test_factor_batch_equals_single_factor_calls_and_pin_route_fixes_the_bits():
+    """medgp_factor_batch == one medgp_factor per entry (same L, z, status, ragged sizes, caller order kept), and with the route
+    pinned (medgp_pin_route) a patient's nlml / gradient / factor do not depend on the batch it is evaluated in: alone (where the
+    library would otherwise take the multi-CU look-ahead schedule) vs among 300 batch-mates (where it would take k_cholinv<4,4>)."""
+    import medgp_amd
+    from medgp_amd import synth
+    D, Q, R = 3, 2, 2
+    ns = [150, 64, 333, 7, 200]
+    pts = [synth.patient(41, s, D, n, interleave=(s % 2 == 1)) for s, n in enumerate(ns)]
+    th = np.stack([synth.theta(41, s, 7, Q, D, R) for s in range(len(ns))])
+    ctx = medgp_amd.Context(7, Q, D, R)
+    ctx.reserve(304, max(ns), 304)
+    ctx.pin_route(True)
+    ctx.set_patients(np.arange(len(ns)), pts)
+    got, st = ctx.factor_batch(np.arange(len(ns)), th, ns)
+    assert np.all(st == 0)
+    for s, n in enumerate(ns):
+        L1, z1, st1 = ctx.factor(s, th[s], n)
+        assert st1 == 0 and np.array_equal(L1, got[s][0]) and np.array_equal(z1, got[s][1])
+        assert np.all(np.triu(got[s][0], 1) == 0.0)
+        m, t, y = pts[s]
+        ref = O.nlml_grad(7, Q, D, R, m, t, y, th[s], want_linv=True)      # caller order: L L^T = K + noise of the caller's ordering
+        Linv = ref["linv"]
+        assert np.max(np.abs(Linv @ got[s][0] - np.eye(n))) < 1e-8
+    # the pinned route: one patient alone vs the same patient as entry 299 of a batch of 300
+    big = synth.patient(43, 0, D, 300)
+    thb = synth.theta(43, 0, 7, Q, D, R)
+    ctx.set_patients(np.arange(300), [big if s == 299 else pts[s % 5] for s in range(300)])
+    tha = np.stack([thb if s == 299 else th[s % 5] for s in range(300)])
+    nl_b, g_b, st_b = ctx.nlml_grad(np.arange(300), tha, True)
+    nl_1, g_1, st_1 = ctx.nlml_grad([299], thb[None, :], True)
+    assert st_b[299] == 0 and st_1[0] == 0
+    assert nl_b[299] == nl_1[0] and np.array_equal(g_b[299], g_1[0])
+    refb = O.nlml_grad(7, Q, D, R, *big, thb)
+    assert abs(nl_1[0] - refb["nlml"]) <= 1e-10 * abs(refb["nlml"])
+    ctx.close()
+
+
+def test_set_priors_rejects_a_duplicate_slot():
+    """Two rows for one slot in a single medgp_set_priors would race in the scatter kernel (advisor finding, round 3): rejected with
+    MEDGP_ERR_ARG, nothing is changed."""
+    P, D, Q, R = 4, 3, 3, 2
+    ctx, pts, th = _ctx(P, D, 70, Q, R)
+    f, ty, ex, p0, p1 = synth.hier_gamma_prior(Q, D, R, 0.01)
+    nl0, g0, _ = ctx.nlml_grad(np.arange(P), th, True)
+    with pytest.raises(capi.MedgpError, match="twice"):
+        ctx.set_priors([1, 2, 1], np.stack([f] * 3), np.stack([ty] * 3), np.stack([ex] * 3), np.stack([p0] * 3), np.stack([p1] * 3))
+    nl1, g1, _ = ctx.nlml_grad(np.arange(P), th, True)
+    assert np.array_equal(nl0, nl1) and np.array_equal(g0, g1)
+    ctx.close()
