@@ -36,8 +36,6 @@ def alg_work(kernel, N, Q, D, H):
     table = {
         "k_prep": (Q * D * D * 2 * 8 + 40.0 * Q * N, 8.0 * (H + 2 * Q * N), "hbm"),
         "k_assemble": (40.0 * pairs, 8.0 * N * N / 2, "mfma"),
-        "k_potrf": (N ** 3 / 3.0 + 2.0 * N * N, 8.0 * N * N, "mfma"),
-        "k_trtri": (N ** 3 / 3.0 + 2.0 * N * N, 8.0 * N * N, "mfma"),
         "k_lauum": (N ** 3 / 3.0 + 2.0 * N * N, 8.0 * N * N, "mfma"),
         "k_gradbins": (40.0 * pairs, 8.0 * N * N / 2, "mfma"),
         # fused Cholesky + triangular inverse + forward solve (potrf N^3/3 + trtri N^3/3 + 2 solves 2N^2);
@@ -46,6 +44,8 @@ def alg_work(kernel, N, Q, D, H):
         # fused W = U U^T - alpha alpha^T (N^3/3) + gradient block sums (40 flop-equivalents per pair);
         # bytes: read U upper once (4N^2)
         "k_wgrad": (N ** 3 / 3.0 + 2.0 * N * N + 40.0 * pairs, 4.0 * N * N, "mfma"),
+        # multi-CU look-ahead schedule (few large patients): the same algorithmic work as k_cholinv, spread over N / 64 launches
+        "k_la_step": (2.0 * N ** 3 / 3.0 + 4.0 * N * N, 12.0 * N * N, "mfma"),
         "k_epilogue": (2.0 * Q * D * D * 8 + 8.0 * H, 8.0 * (2 * H + 3 * Q * D * D), "hbm"),
     }
     return table.get(kernel, (0.0, 0.0, "hbm"))

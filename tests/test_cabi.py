@@ -31,8 +31,8 @@ def test_library_is_gfx950_code_object(built_lib):
     blob = open(built_lib, "rb").read()
     assert b"gfx950" in blob
     assert b"k_cholinv" in blob and b"k_wgrad" in blob and b"k_la_step" in blob
-    # first-generation A/B kernels are not part of the product build (csrc/Makefile: LEGACY=1)
-    assert b"_Z10k_potrf_v0" not in blob and b"_Z10k_ci_panel" not in blob   # (mangled kernel symbols; the profile name table keeps the plain strings)
+    # the first-generation dense kernels left the tree in round 4
+    assert b"k_potrf" not in blob and b"k_ci_panel" not in blob
 
 
 def test_no_cpu_fallback_without_device(built_lib):
