@@ -108,8 +108,8 @@ def test_cohort_list_is_byte_identical_to_one_run_per_patient(tmp_path, built_li
     if not os.path.exists(EXE):
         subprocess.check_call(["make", "-s", "-C", HOST, "medgp_test"])
     Q, D, R = 3, 2, 2
-    pans = ["P101", "P102", "P103"]
-    ex = make_experiment(tmp_path, pans, D=D, Q=Q, R=R, N=[46, 5, 70], opt={"online_learn_rate": 1e-4})
+    pans = ["P101", "P102", "P103", "P104"]      # P102: too few samples for any update; P104: no samples at all (flag file 0)
+    ex = make_experiment(tmp_path, pans, D=D, Q=Q, R=R, N=[46, 5, 70, 0], opt={"online_learn_rate": 1e-4})
     mode = synth.theta(9, 0, 7, Q, D, R)
     mode[D + 1] = 0.0
     fold_dir = os.path.join(ex["dirs"]["kernel"], "fold0")
@@ -121,10 +121,11 @@ def test_cohort_list_is_byte_identical_to_one_run_per_patient(tmp_path, built_li
     base = [EXE, "--cfg", ex["cfg"], "--thread", "1", "--fold", "0", "--kernclust-alg", "gmm"]
     r = subprocess.run(base + ["--pan-list", str(plist), "--max-batch", "64"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "lock-step rounds" in r.stdout and "3 patient(s)" in r.stdout
+    assert "lock-step rounds" in r.stdout and "4 patient(s)" in r.stdout
     tdir = ex["dirs"]["test"]
     cohort = {f: open(os.path.join(tdir, f), "rb").read() for f in sorted(os.listdir(tdir)) if f.startswith("test_")}
-    assert len(cohort) >= 2 * (6 + 6 + 6) - 10      # three patients x two passes x (feature, etime, ci, error, pred, flag)
+    assert len(cohort) == 2 * (6 + 6 + 6 + 1)       # three patients x two passes x (feature, etime, ci, error, pred, flag) + the empty one's flags
+    assert cohort["test_mean_wo_update_flag_P104.txt"] == b"0\n" and cohort["test_mean_w_update_flag_P101.txt"] == b"1\n"
     for f in cohort:
         os.remove(os.path.join(tdir, f))
     for pan in pans:
