@@ -15,6 +15,7 @@
 
 #include "medgp_experiment.hpp"
 #include "medgp_optimizer.hpp"
+#include "medgp_workpool.hpp"
 using namespace medgp;
 typedef std::vector<double> vec;
 typedef std::function<bool(const vec &, double &, vec &)> objective_t;
@@ -249,8 +250,35 @@ static int opt_dump(const char *path) {
     return 0;
 }
 
+// WorkPool (medgp_workpool.hpp): every index runs exactly once, repeatedly, on any number of threads; an exception thrown on a
+// worker thread is rethrown on the calling thread (never std::terminate), the pool stays usable afterwards.
+static int test_pool() {
+    for (int nt : {1, 2, 5, 8}) {
+        medgp::WorkPool pool(nt);
+        for (int rep = 0; rep < 50; rep++) {
+            const int n = 1 + (rep * 37) % 301;
+            std::vector<int> hits(n, 0);
+            pool.parallel_for(n, [&](int i) { hits[i] += 1; });
+            for (int i = 0; i < n; i++) if (hits[i] != 1) { printf("POOL_FAIL threads %d n %d index %d hit %d times\n", nt, n, i, hits[i]); return 1; }
+        }
+        bool caught = false;
+        try {
+            pool.parallel_for(200, [&](int i) { if (i == 137) throw std::runtime_error("boom at 137"); });
+        } catch (const std::runtime_error &e) {
+            caught = std::string(e.what()) == "boom at 137";
+        }
+        if (!caught) { printf("POOL_FAIL exception not propagated (threads %d)\n", nt); return 1; }
+        std::vector<int> hits(64, 0);
+        pool.parallel_for(64, [&](int i) { hits[i] += 1; });          // the pool survives a failed job
+        for (int h : hits) if (h != 1) { printf("POOL_FAIL pool unusable after an exception\n"); return 1; }
+    }
+    printf("POOL_OK usable_cores %d\n", medgp::usable_cores());
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc >= 2 && !strcmp(argv[1], "scg")) return test_scg();
+    if (argc >= 2 && !strcmp(argv[1], "pool")) return test_pool();
     if (argc >= 3 && !strcmp(argv[1], "optdump")) return opt_dump(argv[2]);
     if (argc >= 4 && !strcmp(argv[1], "hyp")) {
         c_experiment e;
