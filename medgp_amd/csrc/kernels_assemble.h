@@ -68,7 +68,10 @@ __device__ __forceinline__ double lane_bcast(double v, int srclane) {
     return __hiloint2double(hi, lo);
 }
 
-template <int QT>
+// QT = mixture components this launch evaluates, Q0 = index of the first one.  Q <= 8: one launch <Q, 0>.  8 < Q <= 16 (Q is a free
+// configuration key of the reference, ref: kernel/c_kernel_LMC_SM.cpp:51-70): <8, 0> followed by <Q - 8, 8>, which ADDS its
+// components to the tile the first launch wrote (components in ascending order, as the reference sums them, :182-191).
+template <int QT, int Q0 = 0>
 __global__ void __launch_bounds__(256) k_assemble_t(MedgpDev L) {
     const int b = blockIdx.y;
     if (L.status[b] < 0) return;
@@ -80,14 +83,14 @@ __global__ void __launch_bounds__(256) k_assemble_t(MedgpDev L) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = L.D;
     const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
-    const double *B = hyp + hyp_off_B(L);
+    const double *B = hyp + hyp_off_B(L) + (size_t)Q0 * D * D;
     const double *t = L.pt + (size_t)slot * ld;
     const int *meta = L.pmeta + (size_t)slot * ld;
-    const double *csb = L.cs + (size_t)b * QT * ld, *snb = L.sn + (size_t)b * QT * ld;
+    const double *csb = L.cs + ((size_t)b * L.Q + Q0) * ld, *snb = L.sn + ((size_t)b * L.Q + Q0) * ld;
     double *K = L.Kmat + (size_t)b * ld * ld;
     double cq2n[QT];   // -c_q log2(e): exp(-c_q dt^2) = 2^(cq2n dt^2)
 #pragma unroll
-    for (int q = 0; q < QT; q++) cq2n[q] = uniform_d(-hyp[hyp_off_c(L) + q] * MEDGP_LOG2E);
+    for (int q = 0; q < QT; q++) cq2n[q] = uniform_d(-hyp[hyp_off_c(L) + Q0 + q] * MEDGP_LOG2E);
     const int j = 64 * J + lane;
     const bool jv = j < n;
     const double tj = t[j];
@@ -130,13 +133,16 @@ __global__ void __launch_bounds__(256) k_assemble_t(MedgpDev L) {
             }
             const double dt = rowc[w][rr][0] - tj, dd = dt * dt;
             double acc = 0.0;
+            if constexpr (Q0 > 0) acc = K[(size_t)i * ld + j];   // the components below Q0 (and the noise) are in the tile already
 #pragma unroll
             for (int q = 0; q < QT; q++) {
                 const v2d csn = *(const v2d *)&rowc[w][rr][2 + 2 * q];
                 const double cd = csn[0] * csj[q] + csn[1] * snj[q];
                 acc += bq[q] * (cd * exp2_nonpos(cq2n[q] * dd));
             }
-            if (i == j) { const double lik = hyp[mj]; acc += lik; for (int r = 0; r < L.jit[b]; r++) acc += lik; }   // ref c_inference_exact.cpp:88-92, :101-104
+            if constexpr (Q0 == 0) {
+                if (i == j) { const double lik = hyp[mj]; acc += lik; for (int r = 0; r < L.jit[b]; r++) acc += lik; }   // ref c_inference_exact.cpp:88-92, :101-104
+            }
             v = jv ? acc : 0.0;
         } else v = (i == j) ? 1.0 : 0.0;
         K[(size_t)i * ld + j] = v;

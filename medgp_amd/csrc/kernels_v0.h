@@ -1,7 +1,7 @@
-// kernels_v0.h -- the generic (non-templated, no MFMA in the pair loops) route for Q > 8 mixture components: k_assemble_v0,
-// k_lauum_v0, k_gradbins_v0 (the tuned kernels are instantiated for Q <= 8; Q is a free configuration key of the reference,
-// ref: kernel/c_kernel_LMC_SM.cpp:51-70).  Checked against the same oracle as the tuned kernels (tests/test_parity_gpu.py, Q = 9);
-// MEDGP_V0=1 selects them for any Q (A/B parity).  The dense stages always run on k_cholinv / the look-ahead schedule.  (The
+// kernels_v0.h -- the generic (non-templated, no MFMA in the pair loops) route for Q > 16 mixture components: k_assemble_v0,
+// k_lauum_v0, k_gradbins_v0 (the tuned kernels cover Q <= 8 in one launch and 9 <= Q <= 16 in two; Q is a free configuration key
+// of the reference, ref: kernel/c_kernel_LMC_SM.cpp:51-70).  Checked against the same oracle as the tuned kernels
+// (tests/test_parity_gpu.py, Q = 17); MEDGP_V0=1 selects them for any Q (A/B parity).  The dense stages always run on k_cholinv / the look-ahead schedule.  (The
 // first-generation dense kernels k_potrf_v0 / k_trtri_v0 and the first multi-CU schedule k_ci_* left the tree in round 4: git
 // history keeps them.)
 #pragma once

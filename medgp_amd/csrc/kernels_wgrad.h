@@ -27,7 +27,9 @@
 #define WG_MINWAVES 3
 #endif
 
-template <int QT>
+// QT = mixture components this launch reduces, Q0 = index of the first one (Q <= 8: one launch <Q, 0>; 8 < Q <= 16: <8, 0> and
+// <Q - 8, 8>, each forming the W tile again -- N^3/3 more MFMA work for a route no BASELINE config takes).
+template <int QT, int Q0 = 0>
 __global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, int nbatch, int ntiles) {
     // staging buffers (phase 1) and the W tile (phase 2/3) share storage
     __shared__ __attribute__((aligned(16))) double smem[2 * 64 * (WG_KC + 2)];
@@ -134,13 +136,14 @@ __global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, i
     const double *alpha = L.alpha + (size_t)b * ld;
     const int *seg = L.pseg + (size_t)slot * (L.D + 1);
     const int *roff = L.proff + (size_t)slot * (L.D + 1), *coff = L.pcoff + (size_t)slot * (L.D + 1);
-    const double *csb = L.cs + (size_t)b * QT * ld, *snb = L.sn + (size_t)b * QT * ld;
+    const double *csb = L.cs + ((size_t)b * L.Q + Q0) * ld, *snb = L.sn + ((size_t)b * L.Q + Q0) * ld;
     double *slab = L.slab + (size_t)b * L.slab_stride;
+    const int Qall = L.Q;   // the slab planes are [S | SM | SV] x ALL components
     const int Rmax = L.slab_R, Cmax = L.slab_C;
 
     double wq[QT], cq[QT];
 #pragma unroll
-    for (int q = 0; q < QT; q++) { wq[q] = hyp[hyp_off_w(L) + q]; cq[q] = hyp[hyp_off_c(L) + q]; }
+    for (int q = 0; q < QT; q++) { wq[q] = hyp[hyp_off_w(L) + Q0 + q]; cq[q] = hyp[hyp_off_c(L) + Q0 + q]; }
     double cq2n[QT];   // -c_q log2(e): exp(-c_q dt^2) = 2^(cq2n dt^2), as in k_assemble_t
 #pragma unroll
     for (int q = 0; q < QT; q++) cq2n[q] = uniform_d(-cq[q] * MEDGP_LOG2E);
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, i
                 }
                 if (seglast && mj >= 0) {
 #pragma unroll
-                    for (int k = 0; k < 3 * QT; k++) slab[((size_t)k * Rmax + rslot) * Cmax + cslot] = fv[k];
+                    for (int k = 0; k < 3 * QT; k++) slab[((size_t)((k / QT) * Qall + Q0 + (k % QT)) * Rmax + rslot) * Cmax + cslot] = fv[k];
                 }
             }
 #pragma unroll

@@ -321,7 +321,11 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         case 6: hipLaunchKernelGGL(k_assemble_t<6>, tg, tb, 0, stream, L); break;
         case 7: hipLaunchKernelGGL(k_assemble_t<7>, tg, tb, 0, stream, L); break;
         case 8: hipLaunchKernelGGL(k_assemble_t<8>, tg, tb, 0, stream, L); break;
-        default: hipLaunchKernelGGL(k_assemble_v0, tg, tb, 0, stream, L); break;
+        // 9 .. 16 components: the first eight, then the rest added to the same tiles (kernels_assemble.h)
+#define MEDGP_ASM2(QR) case 8 + QR: hipLaunchKernelGGL(k_assemble_t<8>, tg, tb, 0, stream, L); hipLaunchKernelGGL((k_assemble_t<QR, 8>), tg, tb, 0, stream, L); break;
+        MEDGP_ASM2(1) MEDGP_ASM2(2) MEDGP_ASM2(3) MEDGP_ASM2(4) MEDGP_ASM2(5) MEDGP_ASM2(6) MEDGP_ASM2(7) MEDGP_ASM2(8)
+#undef MEDGP_ASM2
+        default: hipLaunchKernelGGL(k_assemble_v0, tg, tb, 0, stream, L); break;   // Q > 16 (or MEDGP_V0): generic kernel
         }
     };
     const bool inv = flag_grad || need_inverse;
@@ -407,7 +411,11 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         case 6: hipLaunchKernelGGL(k_wgrad<6>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
         case 7: hipLaunchKernelGGL(k_wgrad<7>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
         case 8: hipLaunchKernelGGL(k_wgrad<8>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
-        default: from_slab = 0; break;   // Q > 8 (or MEDGP_V0): generic kernels below
+        // 9 .. 16 components: two launches, each reducing its own components into its own slab planes (kernels_wgrad.h)
+#define MEDGP_WG2(QR) case 8 + QR: hipLaunchKernelGGL(k_wgrad<8>, tg, tb, 0, stream, L, nbatch, wg_tiles); hipLaunchKernelGGL((k_wgrad<QR, 8>), tg, tb, 0, stream, L, nbatch, wg_tiles); break;
+        MEDGP_WG2(1) MEDGP_WG2(2) MEDGP_WG2(3) MEDGP_WG2(4) MEDGP_WG2(5) MEDGP_WG2(6) MEDGP_WG2(7) MEDGP_WG2(8)
+#undef MEDGP_WG2
+        default: from_slab = 0; break;   // Q > 16 (or MEDGP_V0): generic kernels below
         }
         if (!from_slab) lw.kid = -1;   // nothing was launched under this label: its events go back to the pool unread
         lw.finish();

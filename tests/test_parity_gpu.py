@@ -298,9 +298,11 @@ def test_baseline_config2_full_size():
 
 
 def test_config5_shape_and_many_components():
-    """D = 64 outputs (BASELINE config 5's width; B_q table 164 KB) at a reduced N, and Q = 9 > 8 which takes
-    the generic (non-templated) assembly / gradient kernels."""
-    for (D, N, Q, R) in ((64, 320, 5, 8), (3, 150, 9, 2)):
+    """D = 64 outputs (BASELINE config 5's width; B_q table 164 KB) at a reduced N; Q = 9, 12 and 16 (the tuned pair kernels in two
+    launches: the first eight components, then the rest into the same tiles / their own slab planes) and Q = 17 > 16, which takes
+    the generic (non-templated) assembly / gradient kernels.  Q is a free configuration key of the reference
+    (ref: kernel/c_kernel_LMC_SM.cpp:51-70)."""
+    for (D, N, Q, R) in ((64, 320, 5, 8), (3, 150, 9, 2), (3, 200, 12, 2), (2, 130, 16, 2), (3, 150, 17, 2)):
         pts, th = synth.cohort(303, 2, D, N, Q=Q, R=R)
         ctx = make_ctx(7, Q, D, R, pts)
         nlml, grad, st = ctx.nlml_grad([0, 1], th, True)
