@@ -29,15 +29,23 @@ def loaded(ex, pan, D):
 
 
 def reference_loop(m, t, y, mode, Q, D, R, flag_update, lr, mom, feature_index):
-    """ref main_one_test.cpp:269-444 restated with the oracle as the GP."""
+    return reference_loop_generic(7, Q, D, R, m, t, y, mode, flag_update, lr, mom, feature_index)
+
+
+def reference_loop_generic(kidx, Q, D, R, m, t, y, mode, flag_update, lr, mom, feature_index):
+    """ref main_one_test.cpp:269-444 restated with the oracle as the GP (kidx 7: LMC-SM with the test-time clamp of the
+    exactly-zero A entries, ref c_prior.cpp:118-140; kidx 0 / 8: the single-output families, no test-time prior, m = None)."""
     uniq = np.unique(t)
     best, delta = mode.copy(), np.zeros_like(mode)
     H = mode.size
     clamp = np.zeros(H, bool)
-    clamp[D:D + Q * D * R] = mode[D:D + Q * D * R] == 0.0
+    if kidx == 7:
+        clamp[D:D + Q * D * R] = mode[D:D + Q * D * R] == 0.0
     pr = O.Prior(H)
     pr.flag[clamp] = 1
     pr.type[clamp] = 0
+    mm = np.zeros(t.size, np.int32) if m is None else m
+    sub = (lambda idx: None) if m is None else (lambda idx: m[idx])
     last = uniq[0]
     feat, ci, et, err, pred = [], [], [], [], []
     for tt, tu in enumerate(uniq):
@@ -45,7 +53,7 @@ def reference_loop(m, t, y, mode, Q, D, R, flag_update, lr, mom, feature_index):
         curr = [i for i in range(t.size) if t[i] == tu]
         if flag_update and tt > 3 and np.float32(tu - last) > 5.0 / 60.0:
             last = tu
-            r = O.nlml_grad(7, Q, D, R, m[past], t[past], y[past], best, prior=pr) if len(past) > 2 else {"ok": False}
+            r = O.nlml_grad(kidx, Q, D, R, sub(past), t[past], y[past], best, prior=pr) if len(past) > 2 else {"ok": False}
             if r["ok"]:
                 upd = ~clamp
                 delta[upd] = mom * delta[upd] + lr * r["grad"][upd]
@@ -55,14 +63,14 @@ def reference_loop(m, t, y, mode, Q, D, R, flag_update, lr, mom, feature_index):
         for jj, it in enumerate(curr):
             tr = past + [c for k, c in enumerate(curr) if k != jj]
             if tr:
-                rp = O.fit_predict(7, Q, D, R, m[tr], t[tr], y[tr], best, m[[it]], t[[it]])
+                rp = O.fit_predict(kidx, Q, D, R, sub(tr), t[tr], y[tr], best, sub([it]), t[[it]])
                 mu, var = np.float32(rp["mean"][0]), np.float32(rp["var"][0])
                 e = float(np.float32(mu - y[it]))
                 pred.append(float(mu)); err.append(e); ci.append(int(abs(e) <= 1.96 * np.sqrt(var)))
             else:
                 e = float(np.float32(0.0 - float(y[it])))
-                pred.append(0.0); err.append(0.0 - float(y[it])); ci.append(int(abs(e) <= 1.96 * np.exp(mode[m[it]])))
-            feat.append(feature_index[m[it]]); et.append(float(np.float32(t[it] - tu)))
+                pred.append(0.0); err.append(0.0 - float(y[it])); ci.append(int(abs(e) <= 1.96 * np.exp(mode[mm[it]])))
+            feat.append(feature_index[mm[it]]); et.append(float(np.float32(t[it] - tu)))
     return feat, ci, et, err, pred
 
 

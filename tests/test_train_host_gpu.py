@@ -179,3 +179,78 @@ def test_train_pingpong_groups_and_host_threads_change_nothing(tmp_path, built_l
             for ex, _ in exs[1:]:
                 b = np.fromfile(os.path.join(ex["dirs"]["train"], name + pan + ".bin"), np.float64)
                 assert a.size > 0 and np.array_equal(a, b), (name, pan)
+
+
+@pytest.mark.parametrize("kernel_index", [0, 8])
+def test_single_output_families_through_both_hosts(tmp_path, built_lib, kernel_index):
+    """The reference's mains also run the single-output families (run_model_SE / run_model_SM, ref: main_one_train.cpp:120-152,
+    main_one_test.cpp:144-186).  End to end through the C++ hosts on the device: screening arg-min and the SCG run of medgp_train
+    against the oracle optimiser driven by the oracle objective (bounds in the order config.py:67-100 writes them, random initial
+    hypers of get_hyp_SE / get_hyp_SM), cohort list == single runs byte for byte; then medgp_test (both passes, cohort list) with
+    the trained hypers of the first patient as the mode kernel against the restated imputation loop."""
+    from oracle import optimizer_oracle as OO
+    from test_test_host_gpu import reference_loop_generic
+    for exe in (EXE, os.path.join(HOST, "medgp_test"), os.path.join(HOST, "host_logic_test")):
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-s", "-C", HOST, os.path.basename(exe)])
+    logic = os.path.join(HOST, "host_logic_test")
+    pans, Ns = ["S001", "S002"], [52, 70]
+    Q = 1 if kernel_index == 0 else 3
+    H = 3 if kernel_index == 0 else 1 + 3 * Q
+    ex = make_experiment(tmp_path / "e", pans, Q=Q, N=Ns, kernel_index=kernel_index, opt={"top_iteration_num": 30, "online_learn_rate": 1e-4})
+    ex2 = make_experiment(tmp_path / "c", pans, Q=Q, N=Ns, kernel_index=kernel_index, opt={"top_iteration_num": 30, "online_learn_rate": 1e-4})
+    for pan in pans:
+        run(["--cfg", ex["cfg"], "--pan", pan, "--thread", "1"])
+    plist = tmp_path / "pans.txt"
+    plist.write_text("\n".join(pans) + "\n")
+    run(["--cfg", ex2["cfg"], "--pan-list", str(plist)])
+    hb = tmp_path / "hyp.bin"
+    subprocess.check_call([logic, "hyp", ex["cfg"], str(hb)], stdout=subprocess.DEVNULL)
+    inits = np.fromfile(hb, np.float64).reshape(ex["opt"]["random_init_num"], H)
+    data = {}
+    for pan in pans:
+        for name in ("train_init_hyp_", "train_hyp_"):
+            a = np.fromfile(os.path.join(ex["dirs"]["train"], name + pan + ".bin"), np.float64)
+            b = np.fromfile(os.path.join(ex2["dirs"]["train"], name + pan + ".bin"), np.float64)
+            assert a.size == H and np.array_equal(a, b), (name, pan)
+        db = tmp_path / f"data_{pan}.bin"
+        subprocess.check_call([logic, "data", ex["cfg"], pan, str(db)], stdout=subprocess.DEVNULL)
+        raw = open(db, "rb").read()
+        n = int(np.frombuffer(raw, np.int32, 1)[0])
+        t = np.frombuffer(raw, np.float32, n, 4 + 4 * n).copy()
+        y = np.frombuffer(raw, np.float32, n, 4 + 8 * n).copy()
+        data[pan] = (t, y)
+        best, best_init = np.inf, None
+        for th in inits:
+            r = O.nlml_grad(kernel_index, Q, 1, 0, None, t, y, th, flag_grad=False)
+            assert r["ok"]
+            if r["nlml"] < best:
+                best, best_init = r["nlml"], th
+        assert np.array_equal(np.fromfile(os.path.join(ex["dirs"]["train"], "train_init_hyp_" + pan + ".bin"), np.float64), best_init), pan
+
+        def obj(th):
+            r = O.nlml_grad(kernel_index, Q, 1, 0, None, t, y, np.asarray(th, np.float64), flag_grad=True)
+            return (True, r["nlml"], list(r["grad"])) if r["ok"] else (False, 0.0, [])
+        loss, theta, _ = OO.scg(-30, best_init, obj)
+        got = np.fromfile(os.path.join(ex["dirs"]["train"], "train_hyp_" + pan + ".bin"), np.float64)
+        err = np.abs(got - np.array(theta)) / np.maximum(1.0, np.abs(theta))
+        assert err.max() <= 1e-6, (pan, float(err.max()))
+    # ---- medgp_test with the first patient's trained hypers as the mode kernel
+    mode = np.fromfile(os.path.join(ex["dirs"]["train"], "train_hyp_S001.bin"), np.float64)
+    fold_dir = os.path.join(ex["dirs"]["kernel"], "fold0")
+    os.makedirs(fold_dir)
+    open(os.path.join(fold_dir, "gmm_mode_mixture_num.txt"), "w").write(f"{Q}\n")
+    mode.tofile(os.path.join(fold_dir, "gmm_mode_param.bin"))
+    r = subprocess.run([os.path.join(HOST, "medgp_test"), "--cfg", ex["cfg"], "--pan-list", str(plist), "--fold", "0", "--kernclust-alg", "gmm"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    for pan in pans:
+        t, y = data[pan]
+        for flag_update, mode_name in ((False, "mean_wo_update"), (True, "mean_w_update")):
+            feat, ci, et, err, pred = reference_loop_generic(kernel_index, Q, 1, 0, None, t, y, mode, flag_update, 1e-4, 0.9, ex["feature_index"])
+            pre = os.path.join(ex["dirs"]["test"], f"test_{mode_name}_")
+            gp = np.fromfile(pre + f"pred_{pan}.bin", np.float64)
+            ge = np.fromfile(pre + f"error_{pan}.bin", np.float64)
+            assert gp.size == t.size
+            np.testing.assert_allclose(gp, pred, rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(ge, err, rtol=2e-5, atol=2e-6)
