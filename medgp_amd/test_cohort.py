@@ -81,6 +81,12 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    try:                       # more ranks than GPUs (tests on a one-GPU box): ranks share devices round robin
+        import torch
+        ndev = torch.cuda.device_count()       # (counting devices does not initialise the GPU)
+    except Exception:          # noqa: BLE001
+        ndev = 0
+    device = local_rank % ndev if ndev > 0 else local_rank
 
     cfg = json.load(open(args.cfg))
     pans = [p for p in open(args.pan_list).read().split() if p]
@@ -93,7 +99,7 @@ def main(argv=None):
         with open(shard_file, "w") as f:
             f.write("\n".join(mine) + "\n")
         cmd = [args.exe, "--cfg", args.cfg, "--pan-list", shard_file, "--fold", str(args.fold), "--kernclust-alg", args.kernclust_alg,
-               "--device", str(local_rank)]
+               "--device", str(device)]
         if args.max_batch > 0:
             cmd += ["--max-batch", str(args.max_batch)]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -92,6 +92,12 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    try:                       # more ranks than GPUs (tests on a one-GPU box): ranks share devices round robin
+        import torch
+        ndev = torch.cuda.device_count()       # (counting devices does not initialise the GPU)
+    except Exception:          # noqa: BLE001
+        ndev = 0
+    device = local_rank % ndev if ndev > 0 else local_rank
     dist = None
 
     cfg = json.load(open(args.cfg))
@@ -103,7 +109,7 @@ def main(argv=None):
         shard_file = os.path.join(cfg["exp_train_dir"], f"pan_{tag}.txt")
         with open(shard_file, "w") as f:
             f.write("\n".join(pans[i] for i in idx) + "\n")
-        r = subprocess.run([args.exe, "--cfg", args.cfg, "--pan-list", shard_file, "--device", str(local_rank),
+        r = subprocess.run([args.exe, "--cfg", args.cfg, "--pan-list", shard_file, "--device", str(device),
                             "--max-batch", str(args.max_batch)] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         with open(os.path.join(cfg["exp_train_dir"], f"train_{tag}.log"), "w") as f:
             f.write(r.stdout)
