@@ -151,6 +151,9 @@ __device__ __forceinline__ bool diag16(ld_t *T, ld_t *X, ld_t *dv, ld_t *scr, in
         const double t = T[i * CI_S + c];
         a[c] = ident ? ((c == i) ? 1.0 : 0.0) : t;
     }
+    // (Round 4, measured: branch-free loads -- identity lanes reading a one-hot strip through a per-lane base address, 16 plain
+    //  ds_read instead of 16 exec-mask regions -- make this function 11 % faster in isolation and the look-ahead chain 2 % faster, but
+    //  k_cholinv 7-11 % SLOWER in situ (profiles/r04_diag16_variants.txt); the exec-masked form stays.)
     bool ok = true;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
@@ -201,9 +204,12 @@ __device__ __forceinline__ bool diag16(ld_t *T, ld_t *X, ld_t *dv, ld_t *scr, in
     for (int c = 0; c < 16; c++) a[c] *= readlane_d(rinv, c);
     if (lane < 16) {
         dv[lane] = sq;
+        // whole rows, 16 bytes at a time (round 4): the part right of the diagonal (c > i) receives values nobody reads -- every
+        // consumer of a diagonal tile of L takes its lower triangle only (exports: `cc <= rr`; the tile products read off-diagonal
+        // tiles) -- where a store per column under `c <= i` cost one exec-mask region each.  Same bits; look-ahead chain -2 %,
+        // k_cholinv -0 .. 1.5 % (profiles/r04_diag16_variants.txt).
 #pragma unroll
-        for (int c = 0; c < 16; c++)
-            if (c <= i) T[i * CI_S + c] = a[c];
+        for (int m = 0; m < 8; m++) *(lv2d_t *)&T[i * CI_S + 2 * m] = (v2d){a[2 * m], a[2 * m + 1]};
     } else if (lane < 32) {   // identity rows: a[c] = (L^-T)[i][c] = (L^-1)[c][i], exactly zero for c < i
 #pragma unroll
         for (int c = 0; c < 16; c++) X[c * CI_S + i] = a[c];

@@ -3,7 +3,7 @@ sys.path.insert(0, '/root/repo')
 os.environ['MEDGP_DBG_NOWGRAD']='1'
 import medgp_amd
 from medgp_amd import capi, synth
-capi.lib_path = lambda: '/root/repo/scratch/libmedgp_hip_stamps.so'
+capi.lib_path = lambda: os.environ.get('STAMP_LIB', '/root/repo/scratch/libmedgp_hip_stamps.so')
 D,N,Q,R=24,512,5,8
 P=int(os.environ.get("SP","512"))
 pts, th = synth.cohort(11, 16, D, N, Q=Q, R=R)
