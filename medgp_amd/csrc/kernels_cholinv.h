@@ -137,6 +137,12 @@ __device__ inline void tile_st(ld_t *Cp, v4d c, int li, int g) {
 // a 512-byte LDS scratch and the updates of the columns right of the panel read their four multipliers as broadcast
 // ds_read_b128 pairs -- 60 LDS reads instead of 240 v_readlane per tile.  Every a[c] still receives the same FMAs in the
 // same (ascending j) order: results are bit-identical to the all-readlane form.  scr: 128 doubles of LDS owned by this wave.
+// FL (template): form of the initial loads.  false: `ident ? (c == i) : T[i][c]`, which hipcc turns into one exec-mask region per
+// column; true: identity lanes read their one-hot row from a 31-entry strip Z = [0 x 15, 1, 0 x 15] in the wave's scratch (row i =
+// Z[15 - i .. 30 - i]) and the tile lanes their row of T through ONE per-lane base address: 16 plain ds_read, no select, no branch.
+// Measured (round 4, profiles/r04_diag16_variants.txt): true is 11 % faster in isolation and 2 % on the look-ahead chain, but makes
+// k_cholinv 7-11 % slower in situ -- so the one-wave factor of k_cholinv instantiates false, the four-wave factor true.
+template <bool FL = false>
 __device__ __forceinline__ bool diag16(ld_t *T, ld_t *X, ld_t *dv, ld_t *scr, int lane) {
     // LDL^T order of operations: the column recurrence only needs the RECIPROCAL of each pivot (v_rcp_f64 + two Newton steps,
     // 5 instructions on the serial chain) -- column j stays unscaled, the multipliers are t = a[j] / d_j; the reciprocal
@@ -146,14 +152,21 @@ __device__ __forceinline__ bool diag16(ld_t *T, ld_t *X, ld_t *dv, ld_t *scr, in
     const int i = lane & 15, i5 = lane & 31;
     const bool ident = i5 >= 16;
     double a[16];
+    if constexpr (FL) {
+        // (Z sits in the half of the scratch that the panel loop first writes at panel 1; LDS operations of a wave complete in order)
+        ld_t *Z = scr + 64;
+        if (lane < 31) Z[lane] = (lane == 15) ? 1.0 : 0.0;
+        __builtin_amdgcn_wave_barrier();
+        const ld_t *src = ident ? (const ld_t *)(Z + 15 - i) : (const ld_t *)(T + i * CI_S);
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
-        const double t = T[i * CI_S + c];
-        a[c] = ident ? ((c == i) ? 1.0 : 0.0) : t;
+        for (int c = 0; c < 16; c++) a[c] = src[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const double t = T[i * CI_S + c];
+            a[c] = ident ? ((c == i) ? 1.0 : 0.0) : t;
+        }
     }
-    // (Round 4, measured: branch-free loads -- identity lanes reading a one-hot strip through a per-lane base address, 16 plain
-    //  ds_read instead of 16 exec-mask regions -- make this function 11 % faster in isolation and the look-ahead chain 2 % faster, but
-    //  k_cholinv 7-11 % SLOWER in situ (profiles/r04_diag16_variants.txt); the exec-masked form stays.)
     bool ok = true;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
@@ -383,6 +396,9 @@ __device__ __forceinline__ void trail_tile(ld_t *D, int s2, int u, int t, int li
         c = __builtin_amdgcn_mfma_f64_16x16x4f64(TD(s2, t)[li * CI_S + 4 * k + g], TD(u, t)[li * CI_S + 4 * k + g], c, 0, 0, MFMA_NEGA);
     tile_st(TD(s2, u), c, li, g);
 }
+#ifndef LA_FASTLOADS
+#define LA_FASTLOADS true   // load form of diag16 in the four-wave factor (see diag16)
+#endif
 // (inlined into its callers: as an out-of-line function it claimed 248 VGPRs + 32 AGPRs for callee-saved traffic, and a kernel is
 //  allocated the maximum over its call graph -- k_la_step lost its second workgroup per CU to a callee it runs in one role)
 #define DFW_SETFAIL() do { if (lane == 0) *fail = 1; } while (0)
@@ -402,7 +418,7 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
     if (wave == 0) {
         if (x00) tile_st(TX(0, 0), tile_ld(x00, li, g), li, g);
-        else if (!diag16(TD(0, 0), TX(0, 0), dv, dv + 64, lane)) { DFW_SETFAIL(); }
+        else if (!diag16<LA_FASTLOADS>(TD(0, 0), TX(0, 0), dv, dv + 64, lane)) { DFW_SETFAIL(); }
     }
     FST(0);
     __syncthreads();
@@ -422,7 +438,7 @@ __device__ __forceinline__ void diag_factor_wg(ld_t *D, ld_t *X, ld_t *dv, li_t 
             trail_tile(D, t + 1, t + 1, t, li, g);
             __builtin_amdgcn_wave_barrier();
             FST(2 + 3 * t);
-            if (!diag16(TD(t + 1, t + 1), TX(t + 1, t + 1), dv + 16 * (t + 1), dv + 64, lane)) { DFW_SETFAIL(); }
+            if (!diag16<LA_FASTLOADS>(TD(t + 1, t + 1), TX(t + 1, t + 1), dv + 16 * (t + 1), dv + 64, lane)) { DFW_SETFAIL(); }
             FST(3 + 3 * t);
         } else if (wave < 4) {
             // remaining trailing tiles (s,u), t+1 <= u <= s <= 3, (s,u) != (t+1,t+1): dealt round-robin to waves 1..3

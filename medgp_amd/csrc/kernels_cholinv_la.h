@@ -12,6 +12,9 @@
 //                          for a deep product: everything older than two panels was summed ahead of time by L tasks.
 //     F  (1 per row block) finish panel k: row_r[C_k] = P_r,k X_k^T, then build the pre-solve block of panel k+1:
 //                          P_r,k+1 = init - sum(partials) - row_r[C_k-1] L[C_k+1,C_k-1]^T - row_r[C_k] L[C_k+1,C_k]^T.
+//     H  (1 per patient)   diagonal head start of block k+2 for the NEXT launch's chain:  -K[k+2,k+2] + row[C_k] row[C_k]^T +
+//                          row[C_k-1] row[C_k-1]^T, with row[C_k] re-derived from a copy of the pre-solve block (round 4: this used
+//                          to be the tail of the F task of row block k+2, which made that task as long as the chain).
 //     L  (look-ahead)      for panel k+2 and every row block: partial sums over history slices of LA_SLICE panels
 //                          (columns <= C_k-1, all final before the launch) into a scratch slab -- split-K over as many
 //                          workgroups as the chip has CUs, summed later in a fixed order (bitwise reproducible).
@@ -42,6 +45,9 @@ __host__ __device__ inline int la_slice_len(int k) { return k < 32 ? LA_SLICE : 
 #ifndef LA_D_EARLY
 #define LA_D_EARLY 1      // 1: the chain's wave 0 factors the first 16 x 16 tile of the next diagonal block beside the other waves' rank-64 update (step (5))
 #endif
+#ifndef LA_H_ROLE
+#define LA_H_ROLE 1       // 1: the diagonal head start of block k+2 is formed by a workgroup of its own (H) instead of by the F task of that row block
+#endif
 #ifndef LA_NSUM
 #define LA_NSUM 3         // partial-sum slabs an F task requests per memory round trip
 #endif
@@ -53,6 +59,9 @@ struct LaArgs {
     double *pnx;          // [batch][2][64*64]  copy of the pre-solve block P_k+1,k (row-major), indexed by panel parity: every
                           //                    workgroup of step k re-derives L[C_k+1,C_k] from it while D overwrites the
                           //                    in-place block with the solved values
+    double *pnx2;         // [batch][2][64*64]  copy of the pre-solve block P_k+2,k (row block k+2, panel k), indexed by panel parity: read by the H
+                          //                    workgroup of step k, written one launch earlier by the F workgroup of that row block (which
+                          //                    overwrites the in-place block with the solved values during step k)
     double *dterm;        // [batch][2][64*64]  head start of the NEXT launch's diagonal block, indexed by block parity: -K[blk, blk] + every
                           //                    history term up to the panel finished in this launch, written by the F workgroup of that
                           //                    row block (see k_la_step, "diagonal head start"); element layout of a partial-sum slab
@@ -206,6 +215,11 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
             double *Pn = A.pnx + ((size_t)b * (A.ring + 1) + 0) * 4096;
             for (int e = tid; e < 64 * 64; e += LA_THREADS) Pn[e] = K10[(size_t)(e >> 6) * ld + (e & 63)];
         }
+        if (LA_H_ROLE && cb == 1 && nb > 2) {   // P_2,0 for the H workgroup of step 0
+            const double *K20 = L.Kmat + (size_t)b * ld * ld + (size_t)128 * ld;
+            double *Pn2 = A.pnx2 + ((size_t)b * (A.ring + 1) + 0) * 4096;
+            for (int e = tid; e < 64 * 64; e += LA_THREADS) Pn2[e] = K20[(size_t)(e >> 6) * ld + (e & 63)];
+        }
         return;
     }
     double *Lb = L.Kmat + (size_t)b * ld * ld, *Ub = L.Linv + (size_t)b * ld * ld;
@@ -257,7 +271,7 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
 #endif
 // One task of step k: the body of k_la_step.
 struct LaTask {
-    int role;             // 0 = D (diagonal chain), 1 = F, 2 = L (look-ahead), 3 = R
+    int role;             // 0 = D (diagonal chain), 1 = F, 2 = L (look-ahead), 3 = R, 4 = H (diagonal head start)
     LaRow row;
     int slice;
     bool diag_ahead;
@@ -265,7 +279,7 @@ struct LaTask {
 // slab index of a chain hand-off buffer for step / block x
 __device__ __forceinline__ int la_ring(const LaArgs &A, int x) { return x & A.ring; }
 
-// task index of a step's list (0 = D, 1 .. nF = F, nF + 1 = R, then the L tasks slice-major) -> role; false: empty slot
+// task index of a step's list (0 = D, 1 .. nF = F, nF + 1 = R, nF + 2 = H, then the L tasks slice-major) -> role; false: empty slot
 __device__ __forceinline__ bool la_decode(const LaArgs &A, int k, int want_inv, int task, int nLrowsL, LaTask &T) {
     // the task lists are laid out for the largest patient of the batch (A.nbmax)
     const int nM_F = A.nbmax - (k + 2) > 0 ? A.nbmax - (k + 2) : 0;
@@ -282,6 +296,8 @@ __device__ __forceinline__ bool la_decode(const LaArgs &A, int k, int want_inv, 
         else { T.row.kind = 2; T.row.blk = 0; }
     } else if (task == nF + 1) {
         T.role = 3; T.row.kind = 0; T.row.blk = k + 2;   // R: sum of the diagonal look-ahead slices of block k+2
+    } else if (LA_H_ROLE && task == nF + 2) {
+        T.role = 4; T.row.kind = 0; T.row.blk = k + 2;   // H: diagonal head start of block k+2
     } else {
         T.role = 2;
         // slice-major, and only the ceil(k / la_slice_len(k)) slices that exist at this step are launched: the L tasks that have work
@@ -289,7 +305,7 @@ __device__ __forceinline__ bool la_decode(const LaArgs &A, int k, int want_inv, 
         // maxslice slots per row put the live tasks -- slices 0, 1 of every row early on -- at ids = 0, 1 mod 16, i.e. on TWO
         // of the eight XCDs, behind ~850 empty workgroups: at N = 4096 the L role ended at 49 us of a step whose diagonal
         // chain needs 34 us.)
-        int t = task - 2 - nF;
+        int t = task - 2 - LA_H_ROLE - nF;
         T.slice = t / nLrowsL;
         t -= T.slice * nLrowsL;
         if (T.slice >= A.maxslice) return false;
@@ -328,10 +344,11 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     const bool head_start = is_D && k >= 1;
     v4d acc[4];           // pre-solve block of panel k+1 (non-transposed tiles); the chain's head start lands here directly
     double dsv[16];
-    if (role <= 1 && (is_D || !LA_F_LATE)) {
+    const bool is_H = (role == 4);
+    if ((role <= 1 && (is_D || !LA_F_LATE)) || is_H) {
 #pragma unroll
         for (int e = 0; e < 8; e++) xreg[e] = *(const v2d *)(Xg + 2 * (tid + LA_THREADS * e));
-        la_load_t(A.pnx + ((size_t)b * (A.ring + 1) + la_ring(A, k)) * 4096 + (size_t)(16 * w) * 64, 64, pval, li, g);
+        la_load_t((is_H ? A.pnx2 : A.pnx) + ((size_t)b * (A.ring + 1) + la_ring(A, k)) * 4096 + (size_t)(16 * w) * 64, 64, pval, li, g);
     }
     int n = n_in;
     if (n_in < 0) {
@@ -351,6 +368,45 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     if (row.kind == 0 && row.blk >= nb && !(role == 0)) return 0;   // beyond this patient's blocks
     double *Rb = la_row_base(L, A, b, row);
     LA_TF(0);
+
+    // ============================== H: diagonal head start of block k+2 for the next launch's chain ======================
+    // -K[k+2, k+2] + row[C_k] row[C_k]^T + row[C_k-1] row[C_k-1]^T  with  row[C_k] = P_k+2,k X_k^T  re-derived from the copy the F
+    // workgroup of this row block left one launch ago (the same 40 MFMAs per wave that workgroup runs on the in-place block: same
+    // operands, same order, same bits), then exactly the product / panel sequence that used to be the tail of that F task.
+    if (is_H) {
+        if (k + 2 >= nb) return 0;
+        const int c2 = 64 * (k + 2);
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[ct][r] = -Rb[(size_t)(16 * w + 4 * r + g) * ld + c2 + 16 * ct + li];
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const int idx = 2 * (tid + LA_THREADS * e); *(v2d *)&sm.Xs[idx >> 6][idx & 63] = xreg[e]; }
+        __syncthreads();
+        v4d oh[4];
+        la_trsm(sm.Xs, pval, oh, li, g);
+        __syncthreads();   // every wave is done reading X_k
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) sm.Xs[16 * w + li][16 * ct + 4 * r + g] = oh[ct][r];
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double a = oh[ct][r];
+#pragma unroll
+                for (int cb = 0; cb < 4; cb++)
+                    acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sm.Xs[16 * cb + li][16 * ct + 4 * r + g], acc[cb], 0, 0, 0);
+            }
+        __syncthreads();   // the rows in Xs have been read: la_gemm stages through the same LDS
+        if (k >= 1) la_gemm(Rb, Lb + (size_t)c2 * ld, ld, k - 1, k, acc, sm, tid, w, li, g);
+        double *Dt = A.dterm + ((size_t)b * (A.ring + 1) + la_ring(A, k + 2)) * 4096 + (size_t)w * 1024 + lane;
+#pragma unroll
+        for (int e = 0; e < 16; e++) Dt[e * 64] = acc[e >> 2][e & 3];
+        return 0;
+    }
 
     // ============================== R: diagonal look-ahead slices of block k+2 -> one slab ===============================
     // (slices over panels 0 .. k-2, written by the diag-ahead L tasks of the previous launch; read by the chain of the next launch
@@ -433,10 +489,12 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
         if (head_start) {
             const double *Dt = A.dterm + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096 + (size_t)w * 1024 + lane;
             const double *Ds = A.dsum + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096 + (size_t)w * 1024 + lane;
+            // (with LA_D_EARLY only the tiles left of / on the diagonal -- column tile <= the wave's row tile -- are ever used: the
+            //  others are not requested: 40 of the 64 KB of the two slabs)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] = Dt[e * 64];
+            for (int e = 0; e < 16; e++) if (!LA_D_EARLY || (e >> 2) <= w) acc[e >> 2][e & 3] = Dt[e * 64];
 #pragma unroll
-            for (int e = 0; e < 16; e++) dsv[e] = Ds[e * 64];     // (written by the R workgroup of the previous launch, k >= 1: zeros when there were no slices)
+            for (int e = 0; e < 16; e++) if (!LA_D_EARLY || (e >> 2) <= w) dsv[e] = Ds[e * 64];     // (written by the R workgroup of the previous launch, k >= 1: zeros when there were no slices)
             // (the two slabs are added in front of step (5): their round trip runs under the solve)
         } else if (row.kind != 1) {   // K rows and the y row carry their own initial values in place; U rows start from zero
 #pragma unroll
@@ -522,7 +580,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     // ---- (5) newest rank-64 term: acc += row_r[C_k] L[C_k+1,C_k]^T, straight from the trsm registers (A operand)
     if (head_start) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] += dsv[e];
+        for (int e = 0; e < 16; e++) if (!LA_D_EARLY || (e >> 2) <= w) acc[e >> 2][e & 3] += dsv[e];
     }
 #if !LA_D_EARLY
     const bool d_split = false;
@@ -551,7 +609,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
         }
         if (w == 0) {
             __builtin_amdgcn_wave_barrier();
-            if (!diag16((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.X00[0][0], (ld_t *)sm.dv, (ld_t *)sm.dv + 64, lane)) { if (lane == 0) sm.fail = 1; }
+            if (!diag16<LA_FASTLOADS>((ld_t *)&sm.Xs[0][0], (ld_t *)&sm.X00[0][0], (ld_t *)sm.dv, (ld_t *)sm.dv + 64, lane)) { if (lane == 0) sm.fail = 1; }
         } else {
             // final L[C_k+1, C_k] to memory from the LDS tile (complete since the barrier above; 16-byte accesses, whole lines): by the
             // three waves that would otherwise wait for wave 0 at the next barrier
@@ -578,12 +636,22 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
 #pragma unroll
             for (int r = 0; r < 4; r++) Rb[(size_t)(16 * w + 4 * r + g) * ld + c1 + 16 * ct + li] = -acc[ct][r];
         LA_TF(4);
+#if LA_H_ROLE
+        if (row.kind == 0 && row.blk == k + 3) {   // next step's P_k+3,k+1 for the H workgroup of that step (this task overwrites the in-place block then)
+            double *Pn2 = A.pnx2 + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096;
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) Pn2[(16 * w + 4 * r + g) * 64 + 16 * ct + li] = -acc[ct][r];
+        }
+#endif
         if (row.kind == 0 && row.blk == k + 2) {   // next step's P_k+2,k+1: everybody reads this copy
             double *Pn = A.pnx + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096;
 #pragma unroll
             for (int ct = 0; ct < 4; ct++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) Pn[(16 * w + 4 * r + g) * 64 + 16 * ct + li] = -acc[ct][r];
+#if !LA_H_ROLE
             // diagonal head start for the NEXT launch's chain (row block k+2 is its D role):  -K[k+2, k+2] + row[C_k] row[C_k]^T,
             // this workgroup's 64 rows of panel k (o, final) times themselves.  X_k in Xs is dead (every wave passed the barrier
             // after its trsm), so the rows go there as the shared operand; acc is free again.
@@ -615,6 +683,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
 #pragma unroll
             for (int e = 0; e < 16; e++) Dt[e * 64] = acc[e >> 2][e & 3];
             LA_TF(6);
+#endif
         }
         LA_TEND(1);
         return 0;

@@ -274,7 +274,7 @@ int ensure_la(medgp_ctx *c, int nbatch, int nbmax, LaArgs *out) {
     A.ring = 1;
     const size_t nring = (size_t)A.ring + 1;
     const size_t need_part = (size_t)nbatch * 2 * A.rows * A.maxslice * 4096;
-    const size_t need_small = (size_t)nbatch * (64 * (size_t)c->ldn + 4 * nring * 4096 + 2 * (size_t)A.maxslice * 4096 + 1);
+    const size_t need_small = (size_t)nbatch * (64 * (size_t)c->ldn + 5 * nring * 4096 + 2 * (size_t)A.maxslice * 4096 + 1);
     auto grow = [&](double **p, size_t *cap, size_t need) -> int {
         if (need <= *cap) return MEDGP_OK;
         HIPCHK(c, hipDeviceSynchronize());   // the old scratch may still be read by kernels queued on any of the context's streams
@@ -295,7 +295,8 @@ int ensure_la(medgp_ctx *c, int nbatch, int nbmax, LaArgs *out) {
     A.ybuf = c->d_la_small;
     A.xk2 = c->d_la_small + (size_t)nbatch * 64 * c->ldn;
     A.pnx = A.xk2 + (size_t)nbatch * nring * 4096;
-    A.dterm = A.pnx + (size_t)nbatch * nring * 4096;
+    A.pnx2 = A.pnx + (size_t)nbatch * nring * 4096;
+    A.dterm = A.pnx2 + (size_t)nbatch * nring * 4096;
     A.dsum = A.dterm + (size_t)nbatch * nring * 4096;
     A.dpart = A.dsum + (size_t)nbatch * nring * 4096;
     A.flag = (int *)(A.dpart + (size_t)nbatch * 2 * A.maxslice * 4096);
@@ -364,7 +365,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
                 int nF, nLrows, nsl;
                 step_counts(k, &nF, &nLrows, &nsl);
                 // single entry: park a sleeping workgroup where the dispatcher would put the chain's first neighbour (kernels_cholinv_la.h)
-                const int ntask = 2 + nF + nLrows * nsl;   // D, the F row blocks, R, the look-ahead slices
+                const int ntask = 2 + LA_H_ROLE + nF + nLrows * nsl;   // D, the F row blocks, R, H, the look-ahead slices
                 // (workgroup ids are y * nbatch + x: with nbatch entries the chains are ids 0 .. nbatch-1 and their first neighbours
                 //  ids 256 .. 256+nbatch-1, i.e. task y = 256 / nbatch of every entry)
                 const int pk = (c->la_park > 0 && nbatch <= c->la_park_maxbatch && c->la_park % nbatch == 0) ? c->la_park / nbatch : -1;
