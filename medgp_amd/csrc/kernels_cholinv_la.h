@@ -48,6 +48,16 @@ __host__ __device__ inline int la_slice_len(int k) { return k < 32 ? LA_SLICE : 
 #ifndef LA_H_ROLE
 #define LA_H_ROLE 1       // 1: the diagonal head start of block k+2 is formed by a workgroup of its own (H) instead of by the F task of that row block
 #endif
+#ifndef LA_FOLD_MAX
+#define LA_FOLD_MAX 8     // up to this many diagonal look-ahead slices the H workgroup adds them itself and no R workgroup is launched
+#endif
+// Diagonal look-ahead slices that exist for block k+2 at step k, and who adds them: few slices -> the H workgroup (the chain of the
+// next launch then reads ONE head-start slab: N = 2048 k_la_step 0.700 -> 0.677 ms); many slices (steps > 33 of N = 4096) -> an R
+// workgroup beside H, as rounds 3-4a did (left to H its chain of slab round trips made H the longest task there: 1.86 -> 1.89 ms).
+// A rule of the step alone; the additions are the same either way (slices summed from zero in order, added once): same bits.
+__host__ __device__ inline int la_nsd(int k) { const int sl = la_slice_len(k - 1); return (k >= 2) ? (k - 1 + sl - 1) / sl : 0; }
+__host__ __device__ inline bool la_fold(int k) { return LA_H_ROLE && la_nsd(k) <= LA_FOLD_MAX; }
+#define LA_NAUX(k) ((la_fold(k) ? 0 : 1) + LA_H_ROLE)   // single tasks of step k behind the F row blocks: R and / or H
 #ifndef LA_NSUM
 #define LA_NSUM 3         // partial-sum slabs an F task requests per memory round trip
 #endif
@@ -187,6 +197,31 @@ __device__ __forceinline__ void la_store_t(double *blk, int ld, const v4d (&o)[4
         for (int r = 0; r < 4; r++) blk[(size_t)li * ld + 16 * ct + 4 * r + g] = o[ct][r];
 }
 
+// X_k = L_kk^-1 travels between launches as its ten lower 16 x 16 tiles only (tile-major, tile (tr, tc <= tr) at index tr (tr + 1) / 2 + tc,
+// 256 doubles each: 20 KB instead of 32 KB per D / F / H task and per chain store; the tiles above the diagonal are exact zeros and
+// la_trsm never reads them).  v2d number p of the packed image <-> (row, column pair) of the 64 x 64 matrix:
+#ifndef LA_XPACK
+#define LA_XPACK 1
+#endif
+#define LA_XV2 (LA_XPACK ? 5 : 8)     // 16-byte loads per thread for one X_k
+__device__ __forceinline__ void la_x_rc(int p, int &rr, int &cc) {
+#if LA_XPACK
+    const int tile = p >> 7, within = p & 127;
+    const int tr = (tile >= 1) + (tile >= 3) + (tile >= 6), tc = tile - (tr * (tr + 1)) / 2;
+    rr = 16 * tr + (within >> 3); cc = 16 * tc + 2 * (within & 7);
+#else
+    rr = p >> 5; cc = 2 * (p & 31);
+#endif
+}
+__device__ __forceinline__ void la_x_load(const double *Xg, v2d (&xreg)[8], int tid) {
+#pragma unroll
+    for (int e = 0; e < LA_XV2; e++) xreg[e] = *(const v2d *)(Xg + 2 * (tid + LA_THREADS * e));
+}
+__device__ __forceinline__ void la_x_to_lds(double (*Xs)[LA_S], const v2d (&xreg)[8], int tid) {
+#pragma unroll
+    for (int e = 0; e < LA_XV2; e++) { int rr, cc; la_x_rc(tid + LA_THREADS * e, rr, cc); *(v2d *)&Xs[rr][cc] = xreg[e]; }
+}
+
 // ---- prologue: Y row block <- [y^T; 0], diagonal block 0 factored -> X_0 ------------------------------------------------
 // grid = (nbatch, 1 + nbmax): y = 0 is the diagonal role, y >= 1 initialise 64 columns of the Y block each (y = 1 also
 // seeds the copy of the pre-solve block P_1,0 = K[block 1][C_0])
@@ -234,8 +269,13 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
         const int rr = e >> 6, cc = e & 63;
         if (cc <= rr) Lb[(size_t)rr * ld + cc] = sm.Xs[rr][cc];
         if (want_mode) Ub[(size_t)rr * ld + cc] = (cc >= rr) ? sm.Ls[cc][rr] : 0.0;
+#if !LA_XPACK
         Xg[e] = sm.Ls[rr][cc];
+#endif
     }
+#if LA_XPACK
+    for (int p = tid; p < 1280; p += LA_THREADS) { int rr, cc; la_x_rc(p, rr, cc); *(v2d *)&Xg[2 * p] = *(const v2d *)&sm.Ls[rr][cc]; }
+#endif
     if (tid == 0) L.scal[b * 4 + 0] = sm.logdet;
 }
 
@@ -294,10 +334,10 @@ __device__ __forceinline__ bool la_decode(const LaArgs &A, int k, int want_inv, 
         if (t < nM_F) { T.row.kind = 0; T.row.blk = k + 2 + t; }
         else if (t < nM_F + nU_F) { T.row.kind = 1; T.row.blk = t - nM_F; }
         else { T.row.kind = 2; T.row.blk = 0; }
-    } else if (task == nF + 1) {
+    } else if (!la_fold(k) && task == nF + 1) {
         T.role = 3; T.row.kind = 0; T.row.blk = k + 2;   // R: sum of the diagonal look-ahead slices of block k+2
-    } else if (LA_H_ROLE && task == nF + 2) {
-        T.role = 4; T.row.kind = 0; T.row.blk = k + 2;   // H: diagonal head start of block k+2
+    } else if (LA_H_ROLE && task == nF + LA_NAUX(k)) {
+        T.role = 4; T.row.kind = 0; T.row.blk = k + 2;   // H: diagonal head start of block k+2 (incl. the slices when la_fold(k))
     } else {
         T.role = 2;
         // slice-major, and only the ceil(k / la_slice_len(k)) slices that exist at this step are launched: the L tasks that have work
@@ -305,7 +345,7 @@ __device__ __forceinline__ bool la_decode(const LaArgs &A, int k, int want_inv, 
         // maxslice slots per row put the live tasks -- slices 0, 1 of every row early on -- at ids = 0, 1 mod 16, i.e. on TWO
         // of the eight XCDs, behind ~850 empty workgroups: at N = 4096 the L role ended at 49 us of a step whose diagonal
         // chain needs 34 us.)
-        int t = task - 2 - LA_H_ROLE - nF;
+        int t = task - 1 - LA_NAUX(k) - nF;
         T.slice = t / nLrowsL;
         t -= T.slice * nLrowsL;
         if (T.slice >= A.maxslice) return false;
@@ -346,8 +386,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     double dsv[16];
     const bool is_H = (role == 4);
     if ((role <= 1 && (is_D || !LA_F_LATE)) || is_H) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) xreg[e] = *(const v2d *)(Xg + 2 * (tid + LA_THREADS * e));
+        la_x_load(Xg, xreg, tid);
         la_load_t((is_H ? A.pnx2 : A.pnx) + ((size_t)b * (A.ring + 1) + la_ring(A, k)) * 4096 + (size_t)(16 * w) * 64, 64, pval, li, g);
     }
     int n = n_in;
@@ -380,8 +419,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
         for (int ct = 0; ct < 4; ct++)
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[ct][r] = -Rb[(size_t)(16 * w + 4 * r + g) * ld + c2 + 16 * ct + li];
-#pragma unroll
-        for (int e = 0; e < 8; e++) { const int idx = 2 * (tid + LA_THREADS * e); *(v2d *)&sm.Xs[idx >> 6][idx & 63] = xreg[e]; }
+        la_x_to_lds(sm.Xs, xreg, tid);
         __syncthreads();
         v4d oh[4];
         la_trsm(sm.Xs, pval, oh, li, g);
@@ -402,6 +440,32 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
             }
         __syncthreads();   // the rows in Xs have been read: la_gemm stages through the same LDS
         if (k >= 1) la_gemm(Rb, Lb + (size_t)c2 * ld, ld, k - 1, k, acc, sm, tid, w, li, g);
+        if (la_fold(k)) {   // ... + the diagonal look-ahead slices over panels 0 .. k-2 (written by the L tasks of the previous launch): summed from zero in
+            // slice order and added ONCE, exactly what the R workgroup and the chain's `acc += dsum` did between them -- same bits
+            const int nsd = la_nsd(k);
+            const double *Dp = A.dpart + (((size_t)b * 2 + ((k + 2) & 1)) * A.maxslice) * 4096 + (size_t)w * 1024 + lane;
+            double sacc[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) sacc[e] = 0.0;
+            int sd = 0;
+            for (; sd + 1 < nsd; sd += 2) {
+                double pv[2][16];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) pv[u][e] = Dp[(size_t)(sd + u) * 4096 + e * 64];
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) sacc[e] += pv[u][e];
+            }
+            for (; sd < nsd; sd++) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) sacc[e] += Dp[(size_t)sd * 4096 + e * 64];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e >> 2][e & 3] += sacc[e];
+        }
         double *Dt = A.dterm + ((size_t)b * (A.ring + 1) + la_ring(A, k + 2)) * 4096 + (size_t)w * 1024 + lane;
 #pragma unroll
         for (int e = 0; e < 16; e++) Dt[e * 64] = acc[e >> 2][e & 3];
@@ -493,8 +557,10 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
             //  others are not requested: 40 of the 64 KB of the two slabs)
 #pragma unroll
             for (int e = 0; e < 16; e++) if (!LA_D_EARLY || (e >> 2) <= w) acc[e >> 2][e & 3] = Dt[e * 64];
+            if (!la_fold(k - 1)) {   // (the slab exists only when step k-1 ran an R workgroup)
 #pragma unroll
             for (int e = 0; e < 16; e++) if (!LA_D_EARLY || (e >> 2) <= w) dsv[e] = Ds[e * 64];     // (written by the R workgroup of the previous launch, k >= 1: zeros when there were no slices)
+            }
             // (the two slabs are added in front of step (5): their round trip runs under the solve)
         } else if (row.kind != 1) {   // K rows and the y row carry their own initial values in place; U rows start from zero
 #pragma unroll
@@ -532,8 +598,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
         // F: X_k and the pre-solve copy are requested here, in front of the product of panel k-1 that hides their round trip (held from
         // the top of the task they would take the registers of two of the four slabs in flight above)
         if (!is_D && LA_F_LATE) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) xreg[e] = *(const v2d *)(Xg + 2 * (tid + LA_THREADS * e));
+            la_x_load(Xg, xreg, tid);
             la_load_t(A.pnx + ((size_t)b * (A.ring + 1) + la_ring(A, k)) * 4096 + (size_t)(16 * w) * 64, 64, pval, li, g);
         }
         LA_TF(1);
@@ -541,14 +606,12 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
         if (!head_start && k >= 1 && jf <= k - 1) la_gemm(Rb, Lb + (size_t)c1 * ld, ld, k - 1, k, acc, sm, tid, w, li, g);
     }
     if (!has_next && !is_D && LA_F_LATE) {   // last step: only the solve of panel k is left
-#pragma unroll
-        for (int e = 0; e < 8; e++) xreg[e] = *(const v2d *)(Xg + 2 * (tid + LA_THREADS * e));
+        la_x_load(Xg, xreg, tid);
     }
     LA_TD(3);
     LA_TF(2);
     // ---- (2) X_k -> LDS (Bs is dead: la_gemm ends with a barrier)
-#pragma unroll
-    for (int e = 0; e < 8; e++) { const int idx = 2 * (tid + LA_THREADS * e); *(v2d *)&sm.Xs[idx >> 6][idx & 63] = xreg[e]; }
+    la_x_to_lds(sm.Xs, xreg, tid);
     if (is_D && tid == 0) { sm.fail = 0; sm.logdet = 0.0; }   // (before the first barrier: wave 0 starts factoring ahead of the others, step (5))
     __syncthreads();
     // ---- (3) L[C_k+1, C_k] = P_k+1,k X_k^T for the wave's 16 rows of block k+1 -> LDS (and, D only, to memory)
@@ -578,7 +641,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     LA_TD(4);
     LA_TF(3);
     // ---- (5) newest rank-64 term: acc += row_r[C_k] L[C_k+1,C_k]^T, straight from the trsm registers (A operand)
-    if (head_start) {
+    if (head_start && !la_fold(k - 1)) {
 #pragma unroll
         for (int e = 0; e < 16; e++) if (!LA_D_EARLY || (e >> 2) <= w) acc[e >> 2][e & 3] += dsv[e];
     }
@@ -727,8 +790,15 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
         if (cc + 1 <= rr) *(v2d *)&Lb[(size_t)(c1 + rr) * ld + c1 + cc] = *(const v2d *)&sm.Xs[rr][cc];
         else if (cc == rr) Lb[(size_t)(c1 + rr) * ld + c1 + cc] = sm.Xs[rr][cc];
         if (want_mode) *(v2d *)&Ub[(size_t)(c1 + rr) * ld + c1 + cc] = (v2d){(cc >= rr) ? sm.Ls[cc][rr] : 0.0, (cc + 1 >= rr) ? sm.Ls[cc + 1][rr] : 0.0};
+#if !LA_XPACK
         *(v2d *)&Xn[2 * e] = xv;
+#else
+        (void)xv;
+#endif
     }
+#if LA_XPACK
+    for (int p = tid; p < 1280; p += LA_THREADS) { int rr, cc; la_x_rc(p, rr, cc); *(v2d *)&Xn[2 * p] = *(const v2d *)&sm.Ls[rr][cc]; }
+#endif
     if (tid == 0) L.scal[b * 4 + 0] += sm.logdet;   // the chain's steps are ordered: fixed summation order
     LA_TEND(0);
     return 0;

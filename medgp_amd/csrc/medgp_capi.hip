@@ -365,7 +365,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
                 int nF, nLrows, nsl;
                 step_counts(k, &nF, &nLrows, &nsl);
                 // single entry: park a sleeping workgroup where the dispatcher would put the chain's first neighbour (kernels_cholinv_la.h)
-                const int ntask = 2 + LA_H_ROLE + nF + nLrows * nsl;   // D, the F row blocks, R, H, the look-ahead slices
+                const int ntask = 1 + LA_NAUX(k) + nF + nLrows * nsl;   // D, the F row blocks, R and / or H, the look-ahead slices
                 // (workgroup ids are y * nbatch + x: with nbatch entries the chains are ids 0 .. nbatch-1 and their first neighbours
                 //  ids 256 .. 256+nbatch-1, i.e. task y = 256 / nbatch of every entry)
                 const int pk = (c->la_park > 0 && nbatch <= c->la_park_maxbatch && c->la_park % nbatch == 0) ? c->la_park / nbatch : -1;
