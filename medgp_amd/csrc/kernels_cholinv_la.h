@@ -58,6 +58,9 @@ __host__ __device__ inline int la_slice_len(int k) { return k < 32 ? LA_SLICE : 
 __host__ __device__ inline int la_nsd(int k) { const int sl = la_slice_len(k - 1); return (k >= 2) ? (k - 1 + sl - 1) / sl : 0; }
 __host__ __device__ inline bool la_fold(int k) { return LA_H_ROLE && la_nsd(k) <= LA_FOLD_MAX; }
 #define LA_NAUX(k) ((la_fold(k) ? 0 : 1) + LA_H_ROLE)   // single tasks of step k behind the F row blocks: R and / or H
+#ifndef LA_UKK_BY_F
+#define LA_UKK_BY_F 1     // 1: the diagonal blocks of U are stored by the F task of their row block one launch later, not by the chain
+#endif
 #ifndef LA_NSUM
 #define LA_NSUM 3         // partial-sum slabs an F task requests per memory round trip
 #endif
@@ -628,8 +631,20 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     // ---- (4) own rows of panel k: row_r[C_k] = P_r,k X_k^T   (D: that is the block above, already in o;  U_k: the
     //      diagonal block U_kk itself, final since the previous launch)
     if (!is_D) {
-        if (row.kind == 1 && row.blk == k) la_load_t(oblk, ld, o, li, g);
-        else {
+        if (row.kind == 1 && row.blk == k) {
+#if LA_UKK_BY_F
+            // U_kk = X_k^T is not stored by the chain any more (32 KB less on its store tail): this task, which has X_k in LDS anyway,
+            // derives its rows from it -- the tiles left of the diagonal are zero, the diagonal tile of X_k has exact zeros above its
+            // diagonal -- and stores them; the first readers of this block (history of row block U_k) run one launch later
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[ct][r] = (ct >= w) ? sm.Xs[16 * ct + 4 * r + g][16 * w + li] : 0.0;
+            la_store_t(oblk, ld, o, li, g);
+#else
+            la_load_t(oblk, ld, o, li, g);
+#endif
+        } else {
             v4d oval[4];
             la_load_t(oblk, ld, oval, li, g);
             la_trsm(sm.Xs, oval, o, li, g);
@@ -783,13 +798,16 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
     LA_TD(6);
     if (sm.fail) return 1;
     double *Xn = A.xk2 + ((size_t)b * (A.ring + 1) + la_ring(A, k + 1)) * 4096;
-    // (two columns per lane and store: 16-byte accesses, 8 passes instead of 16 on the tail of the chain)
+    // (two columns per lane and store: 16-byte accesses, 8 passes instead of 16 on the tail of the chain; unrolled, so that the LDS reads
+    //  of all passes are in flight together instead of one read-latency per pass)
+#pragma unroll
     for (int e = tid; e < 64 * 32; e += LA_THREADS) {
         const int rr = e >> 5, cc = 2 * (e & 31);
         const v2d xv = *(const v2d *)&sm.Ls[rr][cc];
         if (cc + 1 <= rr) *(v2d *)&Lb[(size_t)(c1 + rr) * ld + c1 + cc] = *(const v2d *)&sm.Xs[rr][cc];
         else if (cc == rr) Lb[(size_t)(c1 + rr) * ld + c1 + cc] = sm.Xs[rr][cc];
-        if (want_mode) *(v2d *)&Ub[(size_t)(c1 + rr) * ld + c1 + cc] = (v2d){(cc >= rr) ? sm.Ls[cc][rr] : 0.0, (cc + 1 >= rr) ? sm.Ls[cc + 1][rr] : 0.0};
+        // (with U rows in the schedule -- want_mode bit 0 -- the F task of row block U_k+1 stores U_k+1,k+1 in the next launch: LA_UKK_BY_F)
+        if (LA_UKK_BY_F ? (want_mode == 2) : (want_mode != 0)) *(v2d *)&Ub[(size_t)(c1 + rr) * ld + c1 + cc] = (v2d){(cc >= rr) ? sm.Ls[cc][rr] : 0.0, (cc + 1 >= rr) ? sm.Ls[cc + 1][rr] : 0.0};
 #if !LA_XPACK
         *(v2d *)&Xn[2 * e] = xv;
 #else
@@ -797,6 +815,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
 #endif
     }
 #if LA_XPACK
+#pragma unroll
     for (int p = tid; p < 1280; p += LA_THREADS) { int rr, cc; la_x_rc(p, rr, cc); *(v2d *)&Xn[2 * p] = *(const v2d *)&sm.Ls[rr][cc]; }
 #endif
     if (tid == 0) L.scal[b * 4 + 0] += sm.logdet;   // the chain's steps are ordered: fixed summation order
