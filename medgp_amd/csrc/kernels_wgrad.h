@@ -27,9 +27,25 @@
 #define WG_MINWAVES 3
 #endif
 
+// one chunk of the MFMA block of phase 1: rows 16w.. (A fragment ac, streamed) x the four column tiles of the staged J rows
+#define WG_CHUNK_MFMA(ac, buf) \
+    _Pragma("unroll") for (int h = 0; h < 4; h++) \
+        _Pragma("unroll") for (int ct = 0; ct < 4; ct++) { \
+            if (ct > ctmax) continue;   /* diagonal tile: columns right of this wave's rows are never used */ \
+            const v2d bf = *(const v2d *)&Bs[buf][16 * ct + li][8 * h + 2 * g]; \
+            _Pragma("unroll") for (int s = 0; s < 2; s++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[h][s], bf[s], acc[ct], 0, 0, 0); \
+        }
+
 // QT = mixture components this launch reduces, Q0 = index of the first one (Q <= 8: one launch <Q, 0>; 8 < Q <= 16: <8, 0> and
 // <Q - 8, 8>, each forming the W tile again -- N^3/3 more MFMA work for a route no BASELINE config takes).
-template <int QT, int Q0 = 0>
+// PF = chunks the phase-1 loop prefetches ahead.  PF = 2 for launches of few large patients (the chip is filled less than four times): a
+// workgroup then shares its SIMDs with at most a few others and little hides the latency of its operand stream; measured k_wgrad 0.123 ->
+// 0.108 ms (1 x N = 2048), 0.072 -> 0.064 ms (4 x N = 1024), 0.449 -> 0.437 ms (1 x N = 4096), neutral on full launches (which keep PF = 1,
+// the round-3 code path); four chunks ahead and a branch-free MFMA block for the off-diagonal tiles were both slower (DESIGN_LOG A.7).  Such a
+// launch of at most 1024 workgroups (all resident at once, so placement is static: workgroups x, x + 256, x + 512 share a CU -- traced) also
+// deals its tiles in serpentine order, so that the CU holding the longest k range gets the shortest one next.  Scheduling only: same MFMA
+// sequence per tile, same bits.
+template <int QT, int Q0 = 0, int PF = 1>
 __global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, int nbatch, int ntiles) {
     // staging buffers (phase 1) and the W tile (phase 2/3) share storage
     __shared__ __attribute__((aligned(16))) double smem[2 * 64 * (WG_KC + 2)];
@@ -52,9 +68,15 @@ __global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, i
         b = (rest / ntiles) * 8 + xcd;
         tix = rest % ntiles;
     } else {
-        b = blockIdx.x % nbatch;
-        tix = blockIdx.x / nbatch;
-        if (tix >= ntiles) return;
+        int x = blockIdx.x;
+        const int total = nbatch * ntiles;
+        if (x >= total) return;
+        if (PF > 1 && total <= 1024 && ((x >> 8) & 1)) {   // odd group of 256: reversed
+            const int v0 = x & ~255, m = min(256, total - v0);
+            x = v0 + (m - 1 - (x & 255));
+        }
+        b = x % nbatch;
+        tix = x / nbatch;
     }
     if (b >= nbatch) return;
     if (L.status[b] < 0) return;
@@ -85,39 +107,70 @@ __global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, i
         const double *Arow = U + (size_t)(64 * I + 16 * w + li) * ld + k0 + 2 * g;
         const int srow = tid >> 2, scg = (tid & 3) * 8;
         const double *Bsrc = U + (size_t)(64 * J + srow) * ld + k0 + scg;
-        v2d bst[4], an[4];
+        if constexpr (PF == 1) {
+            v2d bst[4], an[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) bst[u] = *(const v2d *)(Bsrc + 2 * u);
+            for (int u = 0; u < 4; u++) bst[u] = *(const v2d *)(Bsrc + 2 * u);
 #pragma unroll
-        for (int h = 0; h < 4; h++) an[h] = *(const v2d *)(Arow + 8 * h);
+            for (int h = 0; h < 4; h++) an[h] = *(const v2d *)(Arow + 8 * h);
 #pragma unroll
-        for (int u = 0; u < 4; u++) *(v2d *)&Bs[0][srow][scg + 2 * u] = bst[u];
-        __syncthreads();
-        for (int c = 0; c < nch; c++) {
-            const int buf = c & 1;
-            v2d ac[4];
-#pragma unroll
-            for (int h = 0; h < 4; h++) ac[h] = an[h];
-            if (c + 1 < nch) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) bst[u] = *(const v2d *)(Bsrc + (c + 1) * WG_KC + 2 * u);
-#pragma unroll
-                for (int h = 0; h < 4; h++) an[h] = *(const v2d *)(Arow + (c + 1) * WG_KC + 8 * h);
-            }
-#pragma unroll
-            for (int h = 0; h < 4; h++)
-#pragma unroll
-                for (int ct = 0; ct < 4; ct++) {
-                    if (ct > ctmax) continue;   // diagonal tile: columns right of this wave's rows are never used
-                    const v2d bf = *(const v2d *)&Bs[buf][16 * ct + li][8 * h + 2 * g];
-#pragma unroll
-                    for (int s = 0; s < 2; s++) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[h][s], bf[s], acc[ct], 0, 0, 0);
-                }
-            if (c + 1 < nch) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) *(v2d *)&Bs[buf ^ 1][srow][scg + 2 * u] = bst[u];
-            }
+            for (int u = 0; u < 4; u++) *(v2d *)&Bs[0][srow][scg + 2 * u] = bst[u];
             __syncthreads();
+            for (int c = 0; c < nch; c++) {
+                const int buf = c & 1;
+                v2d ac[4];
+#pragma unroll
+                for (int h = 0; h < 4; h++) ac[h] = an[h];
+                if (c + 1 < nch) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) bst[u] = *(const v2d *)(Bsrc + (c + 1) * WG_KC + 2 * u);
+#pragma unroll
+                    for (int h = 0; h < 4; h++) an[h] = *(const v2d *)(Arow + (c + 1) * WG_KC + 8 * h);
+                }
+                WG_CHUNK_MFMA(ac, buf);
+                if (c + 1 < nch) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) *(v2d *)&Bs[buf ^ 1][srow][scg + 2 * u] = bst[u];
+                }
+                __syncthreads();
+            }
+        } else {
+            // PF register sets, set s carries the chunks c = s (mod PF): a set is refilled (chunk c + PF) as soon as its A fragment has been
+            // copied out; its staged J rows go to LDS one iteration before they are used (the LDS stays double buffered)
+            v2d bst[PF][4], an[PF][4];
+#pragma unroll
+            for (int st = 0; st < PF; st++)
+                if (st < nch) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) bst[st][u] = *(const v2d *)(Bsrc + st * WG_KC + 2 * u);
+#pragma unroll
+                    for (int h = 0; h < 4; h++) an[st][h] = *(const v2d *)(Arow + st * WG_KC + 8 * h);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; u++) *(v2d *)&Bs[0][srow][scg + 2 * u] = bst[0][u];
+            __syncthreads();
+            for (int c0 = 0; c0 < nch; c0 += PF) {
+#pragma unroll
+                for (int st = 0; st < PF; st++) {
+                    const int c = c0 + st;
+                    if (c >= nch) break;
+                    v2d ac[4];
+#pragma unroll
+                    for (int h = 0; h < 4; h++) ac[h] = an[st][h];
+                    if (c + PF < nch) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) bst[st][u] = *(const v2d *)(Bsrc + (c + PF) * WG_KC + 2 * u);
+#pragma unroll
+                        for (int h = 0; h < 4; h++) an[st][h] = *(const v2d *)(Arow + (c + PF) * WG_KC + 8 * h);
+                    }
+                    WG_CHUNK_MFMA(ac, (st & 1));
+                    if (c + 1 < nch) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) *(v2d *)&Bs[(st + 1) & 1][srow][scg + 2 * u] = bst[(st + 1) % PF][u];
+                    }
+                    __syncthreads();
+                }
+            }
         }
     }
     WSTAMP(0);

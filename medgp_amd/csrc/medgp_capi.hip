@@ -90,6 +90,7 @@ struct medgp_ctx {
     // profiling
     bool profiling = false;
     int profile_only = -1;    // >= 0: only launches of this kernel id are bracketed (medgp_profile_enable(ctx, 2 + id))
+    int wgrad_deep = -1;      // MEDGP_WGRAD_DEEP=1/2: force the prefetch depth of k_wgrad's operand stream (A-B; same bits); -1: by launch size
     bool use_v0 = false;      // MEDGP_V0=1: the generic (non-templated) pair kernels of the Q > 8 route for any Q (debug / A-B parity)
     int cholinv_nw = 0;       // MEDGP_CHOLINV_NW=44|84 forces the workgroup shape <waves, 16-row units per wave> (0 = auto)
     int la_park = 256;        // MEDGP_LA_PARK=<workgroup id>|0: where the look-ahead schedule parks its sleeping workgroup (0 = off)
@@ -403,19 +404,19 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         const dim3 tg(8 * ((nbatch + 7) / 8) * wg_tiles), tb(WG_THREADS);
         from_slab = 1;
         Launcher lw(c, KID_WGRAD, stream);
-        switch (c->use_v0 ? 0 : L.Q) {
-        case 1: hipLaunchKernelGGL(k_wgrad<1>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
-        case 2: hipLaunchKernelGGL(k_wgrad<2>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
-        case 3: hipLaunchKernelGGL(k_wgrad<3>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
-        case 4: hipLaunchKernelGGL(k_wgrad<4>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
-        case 5: hipLaunchKernelGGL(k_wgrad<5>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
-        case 6: hipLaunchKernelGGL(k_wgrad<6>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
-        case 7: hipLaunchKernelGGL(k_wgrad<7>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
-        case 8: hipLaunchKernelGGL(k_wgrad<8>, tg, tb, 0, stream, L, nbatch, wg_tiles); break;
+        // few large patients (the launch fills the chip less than four times): operand prefetch two chunks ahead + serpentine tile order (kernels_wgrad.h)
+        const int pf = c->wgrad_deep >= 0 ? c->wgrad_deep : ((long)nbatch * wg_tiles <= 16L * c->num_cu ? 2 : 1);
+#define MEDGP_WGL(QQ, Q0) do { if (pf >= 2) hipLaunchKernelGGL((k_wgrad<QQ, Q0, 2>), tg, tb, 0, stream, L, nbatch, wg_tiles); \
+                               else hipLaunchKernelGGL((k_wgrad<QQ, Q0, 1>), tg, tb, 0, stream, L, nbatch, wg_tiles); } while (0)
+#define MEDGP_WG1(QQ) case QQ: MEDGP_WGL(QQ, 0); break;
         // 9 .. 16 components: two launches, each reducing its own components into its own slab planes (kernels_wgrad.h)
-#define MEDGP_WG2(QR) case 8 + QR: hipLaunchKernelGGL(k_wgrad<8>, tg, tb, 0, stream, L, nbatch, wg_tiles); hipLaunchKernelGGL((k_wgrad<QR, 8>), tg, tb, 0, stream, L, nbatch, wg_tiles); break;
+#define MEDGP_WG2(QR) case 8 + QR: MEDGP_WGL(8, 0); MEDGP_WGL(QR, 8); break;
+        switch (c->use_v0 ? 0 : L.Q) {
+        MEDGP_WG1(1) MEDGP_WG1(2) MEDGP_WG1(3) MEDGP_WG1(4) MEDGP_WG1(5) MEDGP_WG1(6) MEDGP_WG1(7) MEDGP_WG1(8)
         MEDGP_WG2(1) MEDGP_WG2(2) MEDGP_WG2(3) MEDGP_WG2(4) MEDGP_WG2(5) MEDGP_WG2(6) MEDGP_WG2(7) MEDGP_WG2(8)
+#undef MEDGP_WG1
 #undef MEDGP_WG2
+#undef MEDGP_WGL
         default: from_slab = 0; break;   // Q > 16 (or MEDGP_V0): generic kernels below
         }
         if (!from_slab) lw.kid = -1;   // nothing was launched under this label: its events go back to the pool unread
@@ -527,6 +528,7 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     { const char *e = getenv("MEDGP_LA_PARK_MAXBATCH"); if (e) c->la_park_maxbatch = atoi(e); }
     { const char *e = getenv("MEDGP_MULTI_CU"); c->force_mc = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_STREAMS"); c->nsplit = e ? atoi(e) : 1; }
+    { const char *e = getenv("MEDGP_WGRAD_DEEP"); c->wgrad_deep = e ? std::max(1, atoi(e)) : -1; }
     { const char *e = getenv("MEDGP_DEBUG_FAIL_ATTEMPTS"); c->dbg_fail = e ? atoi(e) : 0; }
     for (int i = 0; i < 2; i++) {
         (void)hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);

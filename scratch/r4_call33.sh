@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 4, GPU call 33: final k_wgrad: bits vs the previous build; then timing A/B on the few-patient shapes
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4c33; mkdir -p $O
+for cfg in "1 2048 24" "3 700 24" "2 1100 8" "64 512 24" "1 4096 64" "4 1024 24" "9 130 3"; do
+  set -- $cfg
+  timeout 300 python3 scratch/dump_eval.py $1 $2 $3 $O/a.npz > /dev/null 2>&1
+  LIB=/root/repo/scratch/libmedgp_prev.so timeout 300 python3 scratch/dump_eval.py $1 $2 $3 $O/b.npz > /dev/null 2>&1
+  python3 -c "
+import numpy as np
+a=np.load('$O/a.npz'); b=np.load('$O/b.npz')
+print('shape $cfg : nlml identical', np.array_equal(a['nl'],b['nl']), ' grad identical', np.array_equal(a['g'],b['g']), 'status', a['st'][:3], b['st'][:3])"
+done
+for round in 1 2 3; do
+  for v in prev new; do
+    for shape in "1 2048 24" "1 4096 64" "4 1024 24" "8 768 24" "2 1536 24"; do
+      if [ $v = new ]; then timeout 300 python3 scratch/qt.py $shape 2>&1 | tail -1 | sed "s/^/r$round $v /" | sed "s/.*\(r[0-9] [a-z0-9]*\) .*\(P[0-9]* N[0-9]* D[0-9]*\).*'k_wgrad': \([0-9.]*\).*wall_ms_per_call \([0-9.]*\)/\1 \2 k_wgrad \3 wall \4/";
+      else LIB=/root/repo/scratch/libmedgp_prev.so timeout 300 python3 scratch/qt.py $shape 2>&1 | tail -1 | sed "s/^/r$round $v /" | sed "s/.*\(r[0-9] [a-z0-9]*\) .*\(P[0-9]* N[0-9]* D[0-9]*\).*'k_wgrad': \([0-9.]*\).*wall_ms_per_call \([0-9.]*\)/\1 \2 k_wgrad \3 wall \4/"; fi
+    done
+  done
+done
