@@ -226,6 +226,7 @@ def other_configs(dev_index, seed, reps=5):
     guarded("screening_1000xN512_D24_nlml_only", lambda: screening(out, dev_index, seed, reps))
     guarded("config4_full_4096xN512_D24", lambda: config4_full(out, dev_index, seed))
     guarded("cohort_mode_kde_P4096_D24_one_cluster", lambda: cohort_kde(out, dev_index, seed))
+    guarded("host_paths", lambda: host_paths(out, dev_index, seed))
     return out
 
 
@@ -254,6 +255,71 @@ def screening(out, dev_index, seed, reps):
                                                 "frac_fp64_peak": (N ** 3 / 3 + 2 * N * N + 40 * Q * N * (N + 1) / 2) * P / dt / 1e12 / FP64_PEAK_TFLOPS,
                                                 "kernel_ms": prof}
     ctx.close()
+
+
+def host_paths(out, dev_index, seed):
+    """The callers either side of the hot path, end to end through the C++ hosts on the reference's file formats:
+    cohort training (`medgp_train --pan-list`: random-init screening + lock-step SCG / varEM, ref: main_one_train.cpp) and the cohort
+    online-imputation test (`medgp_test --pan-list`, both passes, ref: main_one_test.cpp:269-444).  Process wall clock of the
+    executables on a synthetic experiment written here (the writing is not timed); reported beside the headline, never in it."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from medgp_amd import synth
+    from medgp_amd.synth_experiment import make_experiment
+    host = os.path.join(os.path.dirname(os.path.abspath(__file__)), "medgp_amd", "host")
+    tmp = tempfile.mkdtemp(prefix="medgp_bench_host_")
+    try:
+        # ---- f1: 512 patients x N = 512, D = 24, Q = 5, R = 8, prior mode 2; 20 random initialisations, one varEM iteration of 8 SCG steps
+        P, N, D, Q, R = 512, 512, 24, 5, 8
+        pans = [f"P{k:04d}" for k in range(P)]
+        ex = make_experiment(os.path.join(tmp, "train"), pans, D=D, Q=Q, R=R, N=N, feature_index=tuple(range(D)), seed=seed + 3,
+                             opt=dict(random_init_num=20, top_iteration_num=1))
+        plist = os.path.join(tmp, "train_pans.txt")
+        open(plist, "w").write("\n".join(pans) + "\n")
+        t0 = time.perf_counter()
+        r = subprocess.run([os.path.join(host, "medgp_train"), "--cfg", ex["cfg"], "--pan-list", plist, "--thread", "1", "--device", str(dev_index)],
+                           capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError("medgp_train rc %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:]))
+        m1 = re.search(r"optimization finished: (\d+) nlml\+grad evaluations in (\d+) lock-step batches", r.stdout)
+        m2 = re.search(r"lock-step optimisation: ([0-9.e+-]+) s wall \(([0-9.e+-]+) s waiting for the device", r.stdout)
+        nout = len([f for f in os.listdir(ex["dirs"]["train"]) if f.startswith("train_")])
+        out["train_cohort_512xN512_D24"] = {
+            "patients": P, "N": N, "D": D, "random_init_num": 20, "process_wall_s": wall,
+            "gradient_evaluations": int(m1.group(1)) if m1 else None, "lockstep_batches": int(m1.group(2)) if m1 else None,
+            "lockstep_loop_s": float(m2.group(1)) if m2 else None, "device_wait_s": float(m2.group(2)) if m2 else None,
+            "screening_evaluations": 20 * P, "output_files": nout}
+        # ---- f3: 64 test patients, D = 4, N 120 .. 200, both passes (with / without the online hyper updates)
+        P, D, Q, R = 64, 4, 3, 2
+        pans = [f"C{k:03d}" for k in range(P)]
+        ns = [int(v) for v in np.random.default_rng(seed + 4).integers(120, 201, size=P)]
+        ex = make_experiment(os.path.join(tmp, "test"), pans, D=D, Q=Q, R=R, N=ns, feature_index=(18, 19, 20, 21), seed=seed + 4,
+                             opt={"online_learn_rate": 1e-4})
+        fold = os.path.join(ex["dirs"]["kernel"], "fold0")
+        os.makedirs(fold)
+        open(os.path.join(fold, "gmm_mode_mixture_num.txt"), "w").write(f"{Q}\n")
+        synth.theta(9, 0, 7, Q, D, R).tofile(os.path.join(fold, "gmm_mode_param.bin"))
+        plist = os.path.join(tmp, "test_pans.txt")
+        open(plist, "w").write("\n".join(pans) + "\n")
+        t0 = time.perf_counter()
+        r = subprocess.run([os.path.join(host, "medgp_test"), "--cfg", ex["cfg"], "--pan-list", plist, "--thread", "1", "--fold", "0",
+                            "--kernclust-alg", "gmm", "--device", str(dev_index)], capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError("medgp_test rc %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:]))
+        m1 = re.search(r"hyper trajectories: (\d+) gradient evaluations in (\d+) batched calls \((\d+) lock-step rounds\) ([0-9.e+-]+) ms", r.stdout)
+        imps = [int(v) for v in re.findall(r"INFO: (\d+) imputations in", r.stdout)]
+        m3 = re.search(r"pass wall time: without updating ([0-9.e+-]+) ms, with updating ([0-9.e+-]+) ms", r.stdout)
+        out["test_cohort_64xN120-200_D4"] = {
+            "patients": P, "D": D, "process_wall_s": wall,
+            "update_pass_gradient_evaluations": int(m1.group(1)) if m1 else None, "update_pass_rounds": int(m1.group(3)) if m1 else None,
+            "trajectory_ms": float(m1.group(4)) if m1 else None, "imputations_per_pass": imps,
+            "pass_ms_without_update": float(m3.group(1)) if m3 else None, "pass_ms_with_update": float(m3.group(2)) if m3 else None}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def config4_full(out, dev_index, seed, reps=3):
