@@ -61,6 +61,7 @@ struct medgp_ctx {
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     bool pin_pending[2] = {false, false};
     char *h_small = nullptr;               // pinned landing area of the host-pointer operator's results (small calls)
+    char *d_small = nullptr;               // ... and their device image [nlml | grad | status]: ONE copy brings a small call's results back
     MedgpPrior *d_prior_stage = nullptr;   // device staging of medgp_set_prior[s] rows
     int *d_prior_slots = nullptr;
     size_t prior_stage_rows = 0;
@@ -556,6 +557,7 @@ void medgp_destroy(medgp_ctx *c) {
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_bounce) (void)hipHostFree(c->h_bounce);
     if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->d_small) (void)hipFree(c->d_small);
     for (int i = 0; i < 2; i++) {
         if (c->pin_buf[i]) (void)hipHostFree(c->pin_buf[i]);
         if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
@@ -918,18 +920,21 @@ int medgp_nlml_grad(medgp_ctx *c, int nbatch, const int32_t *slots, const double
     const size_t kSmall = (size_t)1 << 20;
     if (th_bytes <= kSmall && out_bytes <= kSmall) {
         if (!c->h_small) HIPCHK(c, hipHostMalloc((void **)&c->h_small, kSmall + 64, hipHostMallocDefault));
+        if (!c->d_small) HIPCHK(c, hipMalloc((void **)&c->d_small, kSmall + 64));
         void *pin = nullptr;
         int rcp = pin_stage(c, th_bytes, &pin);
         if (rcp) return rcp;
         std::memcpy(pin, theta, th_bytes);
         HIPCHK(c, hipMemcpyAsync(c->d_theta, pin, th_bytes, hipMemcpyHostToDevice, c->stream));
-        int rc = medgp_nlml_grad_device(c, nbatch, slots, c->d_theta, flag_grad, c->d_nlml, c->d_grad, c->d_status_out);
+        // the kernels write nlml, gradients and status into ONE device block laid out like the landing area: one copy instead of three
+        // (each copy is a packet of its own on the stream: ~ 4 us apiece behind a 0.4 ms call)
+        double *dn = (double *)c->d_small, *dg = dn + nbatch;
+        int32_t *ds = (int32_t *)(dg + (want_grad ? (size_t)nbatch * H : 0));
+        int rc = medgp_nlml_grad_device(c, nbatch, slots, c->d_theta, flag_grad, dn, want_grad ? dg : nullptr, ds);
         if (rc) return rc;
         double *hn = (double *)c->h_small, *hg = hn + nbatch;
         int32_t *hs = (int32_t *)(hg + (want_grad ? (size_t)nbatch * H : 0));
-        HIPCHK(c, hipMemcpyAsync(hn, c->d_nlml, sizeof(double) * nbatch, hipMemcpyDeviceToHost, c->stream));
-        if (want_grad) HIPCHK(c, hipMemcpyAsync(hg, c->d_grad, sizeof(double) * nbatch * H, hipMemcpyDeviceToHost, c->stream));
-        if (status) HIPCHK(c, hipMemcpyAsync(hs, c->d_status_out, sizeof(int32_t) * nbatch, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hn, dn, out_bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::memcpy(nlml, hn, sizeof(double) * nbatch);
         if (want_grad) std::memcpy(grad, hg, sizeof(double) * nbatch * H);
