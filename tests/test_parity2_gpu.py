@@ -367,3 +367,37 @@ def test_results_do_not_depend_on_batch_size():
     ref = O.nlml_grad(7, Q, D, R, m, t, y, th, prior=O.Prior.hier_gamma(Q, D, R, 0.01))
     assert_parity(n1[0], g1[0], ref, "batch-size invariance")
     ctx.close()
+
+
+def test_beyond_baseline_sizes_the_two_routes_agree(monkeypatch):
+    """One patient larger than any BASELINE config (N = 6000, not a multiple of 64, D = 64: 94 block steps of the look-ahead schedule):
+    the multi-CU look-ahead route and the one-workgroup route share no factorisation code and must agree far inside the parity bars;
+    three gradient components are also checked against Richardson-extrapolated central differences of the device's own nlml.
+    (N = 8192, D = 24 was run once by hand with the same outcome: scratch/big_n_check.py.)"""
+    D, N, Q, R = 64, 6000, 5, 8
+    m, t, y = synth.patient(31, 0, D, N)
+    th = synth.theta(31, 0, 7, Q, D, R)
+    res = {}
+    for route in ("1", "-1"):
+        monkeypatch.setenv("MEDGP_MULTI_CU", route)
+        ctx = medgp_amd.Context(7, Q, D, R)
+        ctx.reserve(1, N, 1)
+        ctx.set_patient(0, m, t, y)
+        nl, g, st = ctx.nlml_grad([0], th[None], True)
+        assert st[0] == 0 and np.isfinite(nl[0]) and np.isfinite(g).all()
+        res[route] = (nl[0], g[0].copy())
+        if route == "1":
+            for h in (0, D + 7, ctx.H - 3):
+                d = []
+                for step in (2e-3, 1e-3):
+                    tp, tm = th.copy(), th.copy()
+                    tp[h] += step
+                    tm[h] -= step
+                    d.append((ctx.nlml_grad([0], tp[None], False)[0][0] - ctx.nlml_grad([0], tm[None], False)[0][0]) / (2 * step))
+                fd = (4 * d[1] - d[0]) / 3
+                assert abs(fd - g[0][h]) <= 1e-6 * max(abs(g[0][h]), 1e-3 * np.abs(g[0]).max()), (h, fd, g[0][h])
+        ctx.close()
+    a, b = res["1"], res["-1"]
+    assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0])
+    gs = np.abs(b[1]).max()
+    assert np.max(np.abs(a[1] - b[1]) / np.maximum(np.abs(b[1]), 1e-3 * gs)) <= 1e-9
