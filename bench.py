@@ -226,8 +226,51 @@ def other_configs(dev_index, seed, reps=5):
     guarded("screening_1000xN512_D24_nlml_only", lambda: screening(out, dev_index, seed, reps))
     guarded("config4_full_4096xN512_D24", lambda: config4_full(out, dev_index, seed))
     guarded("cohort_mode_kde_P4096_D24_one_cluster", lambda: cohort_kde(out, dev_index, seed))
+    guarded("ragged_cohort_300_lognormal_D24", lambda: ragged_cohort(out, dev_index, seed))
     guarded("host_paths", lambda: host_paths(out, dev_index, seed))
     return out
+
+
+def ragged_cohort(out, dev_index, seed, reps=5):
+    """A heavy-tailed cohort in ONE call (round 5): 300 patients, log-normal sizes (synth.ragged_sizes: median ~260, the largest
+    5832 observations), D = 24, hier-gamma prior, nlml + gradient through the host-pointer API.  `after` = the library's default
+    plan (size classes with their own leading dimension, launch geometry and factorisation route, on separate streams);
+    `one_stream` = the same classes back to back; `before` = rounds 1-4 (MEDGP_NO_CLASSES=1: one route for the whole call chosen from
+    its entry count).  frac_fp64_peak = sum_p F_alg(N_p) / time / 78.6 TFLOP/s.  Reference for the behaviour: the job generator buckets
+    patients by size (ref: scripts/slurm_della.json:6-62, medgpc/util/run_exp_generator.py:213-260)."""
+    import medgp_amd
+    from medgp_amd import synth
+    P, D, Q, R = 300, 24, 5, 8
+    pts, th, ns = synth.ragged_cohort(0, P, D, 7, Q, R)
+    f_alg = float(sum(n ** 3 + 6 * n ** 2 + 80 * Q * n * (n + 1) / 2 for n in ns.astype(np.float64)))
+    slots = np.arange(P)
+    res = {}
+    saved = {k: os.environ.get(k) for k in ("MEDGP_CLASS_STREAMS", "MEDGP_NO_CLASSES")}
+    try:
+        for name, env, r in (("after", {}, reps), ("one_stream", {"MEDGP_CLASS_STREAMS": "0"}, reps), ("before", {"MEDGP_NO_CLASSES": "1"}, 1)):
+            for k in saved:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            ctx = medgp_amd.Context(7, Q, D, R, device=dev_index)     # (the switches are read at creation)
+            ctx.reserve(P, int(ns.max()), P)
+            ctx.set_patients(slots, pts)
+            ctx.set_prior(-1, *synth.hier_gamma_prior(Q, D, R, 0.01))
+            nl, g, st = ctx.nlml_grad(slots, th, True)
+            assert np.all(st >= 0) and np.all(np.isfinite(nl)), name
+            t0 = time.perf_counter()
+            for _ in range(r):
+                ctx.nlml_grad(slots, th, True)
+            dt = (time.perf_counter() - t0) / r
+            res[name] = {"ms_per_call": 1e3 * dt, "evals_per_s": P / dt, "frac_fp64_peak": f_alg / dt / 1e12 / FP64_PEAK_TFLOPS,
+                         "plan_count_blocks_route": ctx.last_plan()}
+            ctx.close()
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    out["ragged_cohort_300_lognormal_D24"] = {"patients": P, "D": D, "Q": Q, "R": R, "n_median": int(np.median(ns)), "n_max": int(ns.max()),
+                                              "sum_F_alg": f_alg, **res, "speedup_vs_before": res["before"]["ms_per_call"] / res["after"]["ms_per_call"]}
 
 
 def screening(out, dev_index, seed, reps):

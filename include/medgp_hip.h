@@ -213,6 +213,14 @@ int medgp_kde_mode_at(int device, int nseries, const int64_t *off, const int32_t
  * bytes as one run per patient).  The reference has no such choice: one patient per process, ref: main_one_test.cpp:45-481. */
 int medgp_pin_route(medgp_ctx *ctx, int pinned);
 
+/* How the last medgp_nlml_grad* call was scheduled (diagnostics; round 5).  A call's entries are cut into size classes by their
+ * number of 64-observation blocks, (2^(j-1), 2^j], and every class is given its own launch geometry and factorisation route, the way
+ * the reference's job generator gives patients resources by size (ref: scripts/slurm_della.json:6-62,
+ * medgpc/util/run_exp_generator.py:213-260).  Writes, largest class first and for at most max_classes classes: count[i] entries,
+ * blocks[i] = 64-blocks of its largest entry, route[i] = 0 / 1 one workgroup per entry in the 4- / 8-wave shape, 2 the multi-CU
+ * look-ahead schedule.  Returns the number of classes of the call (possibly > max_classes), or an error code. */
+int medgp_last_plan(const medgp_ctx *ctx, int max_classes, int32_t *count, int32_t *blocks, int32_t *route);
+
 /* block until all work queued on the context's stream is complete */
 int medgp_synchronize(medgp_ctx *ctx);
 

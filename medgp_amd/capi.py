@@ -23,7 +23,7 @@ SYMBOLS = [
     "medgp_num_hyp", "medgp_set_pi", "medgp_set_stream", "medgp_reserve", "medgp_set_patient",
     "medgp_set_patients", "medgp_set_prior", "medgp_set_priors", "medgp_host_alloc", "medgp_host_free", "medgp_nlml_grad_async",
     "medgp_wait", "medgp_nlml_grad", "medgp_nlml_grad_device", "medgp_get_factor",
-    "medgp_factor", "medgp_factor_batch", "medgp_pin_route", "medgp_fit_predict", "medgp_fit_predict_batch", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
+    "medgp_factor", "medgp_factor_batch", "medgp_pin_route", "medgp_last_plan", "medgp_fit_predict", "medgp_fit_predict_batch", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
     "medgp_profile_kernel_name", "medgp_profile_read", "medgp_profile_reset", "medgp_kde_mode", "medgp_kde_mode_at",
 ]
 
@@ -86,6 +86,7 @@ def load():
     lib.medgp_factor.argtypes = [vp, C.c_int, dp, dp, dp, i32p]
     lib.medgp_factor_batch.argtypes = [vp, C.c_int, i32p, dp, C.POINTER(dp), C.POINTER(dp), i32p]
     lib.medgp_pin_route.argtypes = [vp, C.c_int]
+    lib.medgp_last_plan.argtypes = [vp, C.c_int, i32p, i32p, i32p]
     lib.medgp_fit_predict.argtypes = [vp, C.c_int, dp, C.c_int, i32p, fp, fp, fp, i32p]
     lib.medgp_fit_predict_batch.argtypes = [vp, C.c_int, i32p, dp, i32p, fp, fp, fp, i32p]
     lib.medgp_synchronize.argtypes = [vp]
@@ -254,6 +255,15 @@ class Context:
     def pin_route(self, pinned=True):
         """medgp_pin_route: one factorisation kernel for every call, so a patient's bits do not depend on its batch-mates."""
         self._chk(self._lib.medgp_pin_route(self._h, 1 if pinned else 0))
+
+    def last_plan(self):
+        """medgp_last_plan: [(entries, 64-blocks of the largest, route)] of the last nlml_grad call's size classes, largest first;
+        route 0 / 1 = one workgroup per entry (4- / 8-wave shape), 2 = multi-CU look-ahead schedule."""
+        cnt, blk, rt = (np.zeros(32, np.int32) for _ in range(3))
+        nc = self._lib.medgp_last_plan(self._h, 32, _ptr(cnt, C.c_int32), _ptr(blk, C.c_int32), _ptr(rt, C.c_int32))
+        if nc < 0:
+            self._chk(nc)
+        return [(int(cnt[i]), int(blk[i]), int(rt[i])) for i in range(min(nc, 32))]
 
     def nlml_grad(self, slots, theta, flag_grad=True, keep_factor=False):
         """Host-pointer operator. theta: [nbatch, H]. Returns (nlml[nbatch], grad[nbatch,H] or None, status[nbatch]).

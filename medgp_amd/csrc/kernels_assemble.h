@@ -84,8 +84,8 @@ __global__ void __launch_bounds__(256) k_assemble_t(MedgpDev L) {
     const int D = L.D;
     const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
     const double *B = hyp + hyp_off_B(L) + (size_t)Q0 * D * D;
-    const double *t = L.pt + (size_t)slot * ld;
-    const int *meta = L.pmeta + (size_t)slot * ld;
+    const double *t = L.pt + (size_t)slot * L.pld;
+    const int *meta = L.pmeta + (size_t)slot * L.pld;
     const double *csb = L.cs + ((size_t)b * L.Q + Q0) * ld, *snb = L.sn + ((size_t)b * L.Q + Q0) * ld;
     double *K = L.Kmat + (size_t)b * ld * ld;
     double cq2n[QT];   // -c_q log2(e): exp(-c_q dt^2) = 2^(cq2n dt^2)

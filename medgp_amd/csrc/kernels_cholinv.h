@@ -562,7 +562,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
     gd_t *Ub = (gd_t *)(L.Linv + (size_t)b * ld * ld);
     gd_t *zz = (gd_t *)(L.z + (size_t)b * ld);
     gd_t *alpha = (gd_t *)(L.alpha + (size_t)b * ld);
-    const gd_t *y = (const gd_t *)(L.py + (size_t)slot * ld);
+    const gd_t *y = (const gd_t *)(L.py + (size_t)slot * L.pld);
     const int tid = threadIdx.x, lane = tid & 63;
     const int hwave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> scalar control flow + scalar bases
     const int wave = (b & 1) ? (NW - 1 - hwave) : hwave;   // mirrored on odd entries: the diagonal-factor waves of two

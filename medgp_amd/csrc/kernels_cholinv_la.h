@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A
         const int cb = blockIdx.y - 1;
         if (cb >= nb) return;
         double *Y = A.ybuf + (size_t)b * 64 * ld;
-        const double *y = L.py + (size_t)slot * ld;
+        const double *y = L.py + (size_t)slot * L.pld;
         for (int e = tid; e < 64 * 64; e += LA_THREADS) {
             const int rr = e >> 6, cc = 64 * cb + (e & 63);
             Y[(size_t)rr * ld + cc] = (rr == 0 && cc < n) ? y[cc] : 0.0;

@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restri
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int slot = L.bslot[b];
     const int n = L.pn[slot];
-    const double *th = theta + (size_t)b * L.H;
+    const double *th = theta + (size_t)(L.bpos ? L.bpos[b] : b) * L.H;
     double *hyp = L.hyp + (size_t)b * L.hyp_stride;
     double *sig2 = hyp, *B = hyp + hyp_off_B(L), *w = hyp + hyp_off_w(L), *c = hyp + hyp_off_c(L);
     const int Q = L.Q, D = L.D, R = L.R;
@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restri
     if (blockIdx.y >= 1) {
         // ---- cos / sin tables.  theta == nullptr (tables only, medgp_get_factor's caller-order re-factorisation): the
         //      hyper block of this entry is kept, w_q is read from it
-        const double *t = L.pt + (size_t)slot * L.ldn;
+        const double *t = L.pt + (size_t)slot * L.pld;
         double *cs = L.cs + (size_t)b * Q * L.ldn, *sn = L.sn + (size_t)b * Q * L.ldn;
         const int lo = (blockIdx.y - 1) * PREP_CHUNK, hi = min(lo + PREP_CHUNK, Q * L.ldn);
         for (int idx = lo + tid; idx < hi; idx += nt) {
@@ -129,8 +129,8 @@ __device__ __attribute__((noinline)) void reassemble_wg(const MedgpDev &L, int b
     const int ld = L.ldn;
     const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
     const double *cs = L.cs + (size_t)b * L.Q * ld, *sn = L.sn + (size_t)b * L.Q * ld;
-    const double *t = L.pt + (size_t)slot * ld;
-    const int *meta = L.pmeta + (size_t)slot * ld;
+    const double *t = L.pt + (size_t)slot * L.pld;
+    const int *meta = L.pmeta + (size_t)slot * L.pld;
     double *K = L.Kmat + (size_t)b * ld * ld;
     for (int idx = threadIdx.x; idx < np * np; idx += blockDim.x) {
         int i = idx / np, j = idx - i * np;
@@ -234,15 +234,16 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
     const bool own_A = h0 < hA1 && h1 > hA0, own_muv = h0 < hMV1 && h1 > hA1;
     const bool lds_sa = flag_grad && L.kidx == 7 && own_A && Q * D * D <= EPI_S_MAX && Q * D * R <= EPI_A_MAX;
     const int st = L.status[b];
-    double *g = grad_out ? grad_out + (size_t)b * H : nullptr;
-    if (tid == 0 && part == 0 && status_out) status_out[b] = st;
+    const int pos = L.bpos ? L.bpos[b] : b;   // the caller's row of this entry
+    double *g = grad_out ? grad_out + (size_t)pos * H : nullptr;
+    if (tid == 0 && part == 0 && status_out) status_out[pos] = st;
     if (st < 0) {
-        if (tid == 0 && part == 0) nlml_out[b] = __builtin_nan("");
+        if (tid == 0 && part == 0) nlml_out[pos] = __builtin_nan("");
         if (flag_grad && g) for (int h = h0 + tid; h < h1; h += nt) g[h] = __builtin_nan("");
         return;
     }
     const int slot = L.bslot[b], n = L.pn[slot];
-    const double *th = theta + (size_t)b * H;
+    const double *th = theta + (size_t)pos * H;
     const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
     const double *B = hyp + hyp_off_B(L);
     const double *S = L.S + (size_t)b * Q * D * D, *SM = L.SM + (size_t)b * Q * D * D, *SV = L.SV + (size_t)b * Q * D * D;
@@ -423,6 +424,6 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
         }
         double logdet = L.scal[b * 4 + 0], quad = L.scal[b * 4 + 1];
         double nlml = quad / 2.0 + logdet + n * log(2. * L.pi) / 2.0;   // ref: c_inference_exact.cpp:149-152
-        nlml_out[b] = nlml - lp;
+        nlml_out[pos] = nlml - lp;
     }
 }

@@ -64,8 +64,8 @@ __global__ void __launch_bounds__(256) k_predict(MedgpDev L, int nstar, const in
     }
     const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
     const double *B = hyp + hyp_off_B(L), *wq = hyp + hyp_off_w(L), *c = hyp + hyp_off_c(L);
-    const double *t = L.pt + (size_t)slot * ld;
-    const int *meta = L.pmeta + (size_t)slot * ld;
+    const double *t = L.pt + (size_t)slot * L.pld;
+    const int *meta = L.pmeta + (size_t)slot * L.pld;
     const double *zz = L.z + (size_t)b * ld;
     const double *Lm = L.Kmat + (size_t)b * ld * ld, *U = L.Linv + (size_t)b * ld * ld;
     double *v = vs_buf + (size_t)js * ld;

@@ -21,8 +21,8 @@ __global__ void __launch_bounds__(256) k_assemble_v0(MedgpDev L) {
     const int ld = L.ldn;
     const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
     const double *cs = L.cs + (size_t)b * L.Q * ld, *sn = L.sn + (size_t)b * L.Q * ld;
-    const double *t = L.pt + (size_t)slot * ld;
-    const int *meta = L.pmeta + (size_t)slot * ld;
+    const double *t = L.pt + (size_t)slot * L.pld;
+    const int *meta = L.pmeta + (size_t)slot * L.pld;
     double *K = L.Kmat + (size_t)b * ld * ld;
     const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
     for (int a = 0; a < 4; a++)
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) k_gradbins_v0(MedgpDev L) {
     const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
     const double wq = hyp[hyp_off_w(L) + q], cq = hyp[hyp_off_c(L) + q];
     const double *cs = L.cs + ((size_t)b * Q + q) * ld, *sn = L.sn + ((size_t)b * Q + q) * ld;
-    const double *t = L.pt + (size_t)slot * ld;
+    const double *t = L.pt + (size_t)slot * L.pld;
     const double *W = L.Kmat + (size_t)b * ld * ld;
     const int r0 = seg[d], r1 = seg[d + 1], c0 = seg[e], c1 = seg[e + 1];
     double aS = 0.0, aM = 0.0, aV = 0.0;

@@ -184,8 +184,8 @@ __global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, i
     WSTAMP(1);
     // ---------------- phase 3
     const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
-    const double *t = L.pt + (size_t)slot * ld;
-    const int *meta = L.pmeta + (size_t)slot * ld;
+    const double *t = L.pt + (size_t)slot * L.pld;
+    const int *meta = L.pmeta + (size_t)slot * L.pld;
     const double *alpha = L.alpha + (size_t)b * ld;
     const int *seg = L.pseg + (size_t)slot * (L.D + 1);
     const int *roff = L.proff + (size_t)slot * (L.D + 1), *coff = L.pcoff + (size_t)slot * (L.D + 1);

@@ -30,6 +30,32 @@ thread_local std::string g_create_error;   // last medgp_create error of the cal
 
 struct EvPair { int kid; hipEvent_t a, b; };
 
+// ---- the plan of a call (round 5) --------------------------------------------------------------------------------------------
+// A call's entries are ordered by size internally and cut into SIZE CLASSES (64-block count in (2^(j-1), 2^j]): every class is a view
+// of the batch buffers with its own leading dimension (the class's largest n rounded up to 64), its own launch geometry and its own
+// factorisation route, and the classes of one call run beside each other on separate streams.  Why: the reference gives patients
+// resources by size (ref: scripts/slurm_della.json:6-62, medgpc/util/run_exp_generator.py:213-260); rounds 1-4 chose ONE route per
+// call from the call's largest patient, so one N ~ 6000 patient in a batch of 300 ran on one workgroup and set the time of the call.
+enum Route { ROUTE_WG44 = 0, ROUTE_WG84 = 1, ROUTE_LA = 2 };
+struct SizeClass {
+    int b0 = 0, count = 0;     // internal entries [b0, b0 + count)
+    int nbmax = 1;             // 64-blocks of the class's largest entry
+    int ld = 64;               // leading dimension of the class view
+    size_t off_mat = 0, off_vec = 0, off_tab = 0, off_slab = 0;   // offsets (doubles) of the class inside Kmat/Linv, z/alpha/wdiag, cs/sn, slab
+    long long tsum = 0;        // sum of the cost model over its entries (route rule)
+    int route = ROUTE_WG84;    // last route taken (diagnostics: medgp_debug_plan)
+};
+struct BatchPlan {
+    bool sorted = false;       // false: the legacy layout -- one class, caller order, leading dimension = the context's (predict / factor exports)
+    bool identity = true;      // internal order == caller order
+    std::vector<int> order;    // internal index -> caller index
+    std::vector<int> inv;      // caller index -> internal index
+    std::vector<int> en;       // n of every entry, internal order
+    std::vector<SizeClass> cls;
+    size_t need_mat = 0, need_vec = 0, need_tab = 0, need_slab = 0;   // doubles the call needs of each arena
+};
+constexpr int kAuxStreams = 4;
+
 }  // namespace
 
 struct medgp_ctx {
@@ -69,8 +95,15 @@ struct medgp_ctx {
     std::vector<int> h_n;
     std::vector<std::vector<int>> h_perm;   // internal index -> caller index
     std::vector<uint8_t> h_perm_identity;
-    std::vector<int> h_bslot;
+    std::vector<int> h_bslot;       // effective slots of the last call, CALLER order
     int last_nbatch = 0;
+    bool last_sorted = false;
+    BatchPlan plan;                 // of the last call
+    // arenas of the per-entry buffers (Kmat | Linv, z | alpha | wdiag, cs | sn, slab): what medgp_reserve's capacities would need at
+    // most (full_*), what is allocated (cap_*).  Up to kArenaEager bytes they are allocated by medgp_reserve; beyond that (a ragged
+    // cohort whose largest patient is far above the median: max_batch x max_n^2 would not fit 288 GB) they grow with the calls.
+    size_t full_mat = 0, full_vec = 0, full_tab = 0, full_slab = 0, cap_mat = 0, cap_vec = 0, cap_tab = 0, cap_slab = 0;
+    int *d_bpos = nullptr;
     bool last_has_inverse = false;   // the last pipeline run formed alpha and U = L^-T (medgp_get_factor is valid)
     // upload staging (one pinned host buffer + one device buffer, reused; guarded by ev_stage)
     char *h_stage = nullptr, *d_stage = nullptr;
@@ -100,9 +133,10 @@ struct medgp_ctx {
     int pin_route = 0;        // medgp_pin_route: every entry is factored by k_cholinv<8,4> whatever the batch (reproducible bits)
     int num_cu = 256;
     int dbg_fail = 0;         // MEDGP_DEBUG_FAIL_ATTEMPTS=k: test hook, see MedgpDev::dbg_fail
-    int nsplit = 1;           // MEDGP_STREAMS=2 splits large batches over two streams (measured: 98.9k vs 104.6k evals/s -> off)
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    int class_streams = kAuxStreams;   // MEDGP_CLASS_STREAMS=0: the size classes of a call run back to back on the call's stream (A-B)
+    int no_classes = 0;       // MEDGP_NO_CLASSES=1: rounds 1-4 behaviour -- one class per call, one route from its largest entry (A-B)
+    hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<EvPair> events;
     std::vector<hipEvent_t> ev_pool;   // recycled timing events: a profiled launch creates none once the pool is warm
     double prof_ms[KID_COUNT] = {0};
@@ -222,9 +256,18 @@ int pin_stage(medgp_ctx *c, size_t bytes, void **out) {
     return MEDGP_OK;
 }
 
-// Select the batch.  caller_order: entries whose patient was not uploaded grouped by output use the caller-order copy of
-// the patient (slot + max_slots), so that the factor is the one the caller's order defines (no gradient on that copy).
-int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bool caller_order = false) {
+inline int tri(int n) { return n * (n + 1) / 2; }
+inline int blocks64(int n) { return (std::max(n, 1) + 63) / 64; }
+// size class of an entry of nb 64-blocks: 0 -> {1}, 1 -> {2}, 2 -> {3, 4}, 3 -> {5 .. 8}, ...
+inline int size_bucket(int nb) { int j = 0; while ((1 << j) < nb) j++; return j; }
+// Cost model of one entry on ONE workgroup (k_cholinv), fitted to profiles/r04_route_table.txt (ms = 4.4e-4 nb^2 (nb + 17):
+// N = 256 0.15, 512 0.70, 768 1.83, 1024 3.7; N = 8192: 1.05 s against 1.33 s measured).  Integer, so the route rule is exact.
+inline long long wg_cost(int nb) { return (long long)nb * nb * (nb + 17); }
+
+// Select the batch and lay out its plan.  caller_order: entries whose patient was not uploaded grouped by output use the caller-order
+// copy of the patient (slot + max_slots), so that the factor is the one the caller's order defines (no gradient on that copy).
+// sorted: the operator's layout (size classes, see BatchPlan); otherwise the legacy one-class layout the exports read.
+int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bool caller_order = false, bool sorted = false) {
     if (nbatch < 1 || nbatch > c->max_batch) return fail(c, MEDGP_ERR_CAPACITY, "nbatch %d outside [1, %d]", nbatch, c->max_batch);
     int mx = 0;
     std::vector<int> eff(nbatch);
@@ -235,22 +278,101 @@ int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bo
         eff[b] = (caller_order && !c->h_perm_identity[s]) ? s + c->max_slots : s;
     }
     *max_n_out = mx;
-    bool same = (nbatch == c->last_nbatch) && std::memcmp(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch) == 0;
-    if (!same) {
-        std::memcpy(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch);
-        // the table travels through the pinned ring: no wait for the device (the lock-step optimiser changes the active set on
-        // most steps; stream order puts the copy behind the kernels of the previous call that still read the old table)
-        void *pin = nullptr;
-        int rcp = pin_stage(c, sizeof(int) * nbatch, &pin);
-        if (rcp) return rcp;
-        std::memcpy(pin, eff.data(), sizeof(int) * nbatch);
-        HIPCHK(c, hipMemcpyAsync(c->d_bslot, pin, sizeof(int) * nbatch, hipMemcpyHostToDevice, c->stream));
-        c->last_nbatch = nbatch;
+    bool same = (nbatch == c->last_nbatch) && sorted == c->last_sorted && std::memcmp(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch) == 0;
+    if (same) return MEDGP_OK;
+    std::memcpy(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch);
+    BatchPlan &P = c->plan;
+    P.sorted = sorted;
+    P.order.resize(nbatch); P.inv.resize(nbatch); P.en.resize(nbatch);
+    P.cls.clear();
+    for (int b = 0; b < nbatch; b++) P.order[b] = b;
+    auto nof = [&](int b) { return c->h_n[slots[b]]; };
+    const bool classes = sorted && !c->no_classes;
+    // by 64-block count, largest first (what the hardware dispatches first runs longest: LPT inside every launch); ties keep the caller's order
+    if (classes) std::stable_sort(P.order.begin(), P.order.end(), [&](int a, int b) { return blocks64(nof(a)) > blocks64(nof(b)); });
+    P.identity = true;
+    for (int i = 0; i < nbatch; i++) { P.inv[P.order[i]] = i; P.en[i] = nof(P.order[i]); P.identity = P.identity && P.order[i] == i; }
+    const size_t Q = c->Q, D = c->D;
+    size_t om = 0, ov = 0, ot = 0, os = 0;
+    for (int i = 0; i < nbatch;) {
+        SizeClass k;
+        k.b0 = i;
+        const int bk = size_bucket(blocks64(P.en[i]));
+        int j = i;
+        while (j < nbatch && (!classes || size_bucket(blocks64(P.en[j])) == bk)) { k.tsum += wg_cost(blocks64(P.en[j])); k.nbmax = std::max(k.nbmax, blocks64(P.en[j])); j++; }
+        if (!classes) k.nbmax = blocks64(mx);
+        k.count = j - i;
+        k.ld = sorted ? 64 * k.nbmax : c->ldn;
+        k.off_mat = om; k.off_vec = ov; k.off_tab = ot; k.off_slab = os;
+        om += (size_t)k.count * k.ld * k.ld; ov += (size_t)k.count * k.ld; ot += (size_t)k.count * Q * k.ld;
+        os += (size_t)k.count * 3 * Q * (k.ld / 16 + D) * (k.ld / 64 + D);
+        P.cls.push_back(k);
+        i = j;
     }
+    P.need_mat = om; P.need_vec = ov; P.need_tab = ot; P.need_slab = os;
+    // the tables travel through the pinned ring: no wait for the device (the lock-step optimiser changes the active set on
+    // most steps; stream order puts the copy behind the kernels of the previous call that still read the old tables)
+    const bool need_pos = !(P.identity && P.cls.size() == 1);
+    void *pin = nullptr;
+    int rcp = pin_stage(c, sizeof(int) * nbatch * (need_pos ? 2 : 1), &pin);
+    if (rcp) return rcp;
+    int *hp = (int *)pin;
+    for (int i = 0; i < nbatch; i++) hp[i] = eff[P.order[i]];
+    HIPCHK(c, hipMemcpyAsync(c->d_bslot, hp, sizeof(int) * nbatch, hipMemcpyHostToDevice, c->stream));
+    if (need_pos) {
+        for (int i = 0; i < nbatch; i++) hp[nbatch + i] = P.order[i];
+        HIPCHK(c, hipMemcpyAsync(c->d_bpos, hp + nbatch, sizeof(int) * nbatch, hipMemcpyHostToDevice, c->stream));
+    }
+    c->last_nbatch = nbatch;
+    c->last_sorted = sorted;
     return MEDGP_OK;
 }
 
-inline int tri(int n) { return n * (n + 1) / 2; }
+// the view of the batch buffers one size class works in (entry 0 of the view = internal entry k.b0)
+MedgpDev class_view(const medgp_ctx *c, const SizeClass &k) {
+    const MedgpDev &L = c->dev;
+    MedgpDev V = L;
+    const size_t Q = L.Q, D = L.D, b0 = k.b0;
+    V.ldn = k.ld;
+    V.slab_R = k.ld / 16 + (int)D; V.slab_C = k.ld / 64 + (int)D;
+    V.slab_stride = (size_t)3 * Q * V.slab_R * V.slab_C;
+    V.bslot = L.bslot + b0;
+    V.bpos = (c->plan.identity && c->plan.cls.size() == 1) ? nullptr : c->d_bpos + b0;
+    V.hyp = L.hyp + b0 * L.hyp_stride;
+    V.cs = L.cs + k.off_tab; V.sn = L.sn + k.off_tab;
+    V.Kmat = L.Kmat + k.off_mat; V.Linv = L.Linv + k.off_mat;
+    V.z = L.z + k.off_vec; V.alpha = L.alpha + k.off_vec; V.wdiag = L.wdiag + k.off_vec;
+    V.epi_lp = L.epi_lp + b0 * MEDGP_EPI_PARTS; V.epi_ticket = L.epi_ticket + b0;
+    V.scal = L.scal + b0 * 4; V.status = L.status + b0; V.jit = L.jit + b0; V.bn = L.bn + b0; V.xk = L.xk + b0 * 64 * 64;
+    V.S = L.S + b0 * Q * D * D; V.SM = L.SM + b0 * Q * D * D; V.SV = L.SV + b0 * Q * D * D;
+    V.slab = L.slab + k.off_slab;
+    return V;
+}
+
+// view of the batch-indexed buffers starting at entry b0 of the view L
+MedgpDev shifted_view(const MedgpDev &L, int b0) {
+    MedgpDev V = L;
+    const size_t ld = L.ldn, Q = L.Q, D = L.D;
+    V.bslot = L.bslot + b0;
+    if (L.bpos) V.bpos = L.bpos + b0;
+    V.hyp = L.hyp + (size_t)b0 * L.hyp_stride;
+    V.cs = L.cs + (size_t)b0 * Q * ld; V.sn = L.sn + (size_t)b0 * Q * ld;
+    V.Kmat = L.Kmat + (size_t)b0 * ld * ld; V.Linv = L.Linv + (size_t)b0 * ld * ld;
+    V.z = L.z + (size_t)b0 * ld; V.alpha = L.alpha + (size_t)b0 * ld; V.wdiag = L.wdiag + (size_t)b0 * ld;
+    V.epi_lp = L.epi_lp + (size_t)b0 * MEDGP_EPI_PARTS; V.epi_ticket = L.epi_ticket + b0;
+    V.scal = L.scal + (size_t)b0 * 4; V.status = L.status + b0; V.jit = L.jit + b0; V.bn = L.bn + b0; V.xk = L.xk + (size_t)b0 * 64 * 64;
+    V.S = L.S + (size_t)b0 * Q * D * D; V.SM = L.SM + (size_t)b0 * Q * D * D; V.SV = L.SV + (size_t)b0 * Q * D * D;
+    V.slab = L.slab + (size_t)b0 * L.slab_stride;
+    return V;
+}
+
+// the one-entry view of CALLER entry b of the last call
+MedgpDev entry_view(const medgp_ctx *c, int b) {
+    const int i = c->plan.inv[b];
+    for (const SizeClass &k : c->plan.cls)
+        if (i >= k.b0 && i < k.b0 + k.count) return shifted_view(class_view(c, k), i - k.b0);
+    return c->dev;   // (not reached: every entry belongs to a class)
+}
 
 // device -> host copy of `bytes` through a pinned bounce buffer (a pageable hipMemcpy of this size pays ~10 ms of one-time
 // runtime staging set-up on its first use); returns the pinned pointer, valid until the next call
@@ -267,16 +389,45 @@ int d2h_pinned(medgp_ctx *c, const void *dev, size_t bytes, const char **out) {
     return MEDGP_OK;
 }
 
-// scratch of the look-ahead factorisation for `nbatch` entries of at most `nbmax` 64-blocks (freed by free_all)
-int ensure_la(medgp_ctx *c, int nbatch, int nbmax, LaArgs *out) {
-    LaArgs A{};
-    A.nbmax = nbmax;
-    A.maxslice = (nbmax + LA_SLICE - 1) / LA_SLICE;
-    A.rows = 2 * nbmax + 1;
-    A.ring = 1;
-    const size_t nring = (size_t)A.ring + 1;
-    const size_t need_part = (size_t)nbatch * 2 * A.rows * A.maxslice * 4096;
-    const size_t need_small = (size_t)nbatch * (64 * (size_t)c->ldn + 5 * nring * 4096 + 2 * (size_t)A.maxslice * 4096 + 1);
+// the arenas of the per-entry buffers, grown on demand (see medgp_ctx::full_mat); a growth waits for the device and drops the
+// factors of earlier calls
+constexpr size_t kArenaEager = (size_t)8 << 30;
+int ensure_arena(medgp_ctx *c, size_t need_mat, size_t need_vec, size_t need_tab, size_t need_slab) {
+    MedgpDev &L = c->dev;
+    auto grow = [&](size_t need, size_t full, size_t *cap, std::initializer_list<double **> bufs) -> int {
+        if (need <= *cap) return MEDGP_OK;
+        HIPCHK(c, hipDeviceSynchronize());
+        const size_t want = std::min(std::max(need, *cap + *cap / 2), std::max(full, need));
+        for (double **p : bufs) {
+            if (*p) {
+                (void)hipFree(*p);
+                c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), (void *)*p), c->allocs.end());
+                *p = nullptr;
+            }
+        }
+        *cap = 0;
+        for (double **p : bufs) { int rc = dalloc(c, p, want); if (rc) return rc; }
+        *cap = want;
+        c->last_has_inverse = false;
+        return MEDGP_OK;
+    };
+    int rc;
+    if ((rc = grow(need_mat, c->full_mat, &c->cap_mat, {&L.Kmat, &L.Linv}))) return rc;
+    if ((rc = grow(need_vec, c->full_vec, &c->cap_vec, {&L.z, &L.alpha, &L.wdiag}))) return rc;
+    if ((rc = grow(need_tab, c->full_tab, &c->cap_tab, {&L.cs, &L.sn}))) return rc;
+    if ((rc = grow(need_slab, c->full_slab, &c->cap_slab, {&L.slab}))) return rc;
+    return MEDGP_OK;
+}
+
+// scratch of the look-ahead factorisation for the classes of a call that take it (freed by free_all): one allocation pair, carved up
+// per class -- the classes run on different streams
+struct LaNeed { int count, nbmax, ld; LaArgs A; };
+int ensure_la(medgp_ctx *c, std::vector<LaNeed> &v) {
+    const size_t nring = 2;
+    size_t need_part = 0, need_small = 0;
+    auto part_of = [&](const LaNeed &e) { return (size_t)e.count * 2 * (2 * e.nbmax + 1) * ((e.nbmax + LA_SLICE - 1) / LA_SLICE) * 4096; };
+    auto small_of = [&](const LaNeed &e) { return (size_t)e.count * (64 * (size_t)e.ld + 5 * nring * 4096 + 2 * (size_t)((e.nbmax + LA_SLICE - 1) / LA_SLICE) * 4096 + 1); };
+    for (const LaNeed &e : v) { need_part += part_of(e); need_small += small_of(e); }
     auto grow = [&](double **p, size_t *cap, size_t need) -> int {
         if (need <= *cap) return MEDGP_OK;
         HIPCHK(c, hipDeviceSynchronize());   // the old scratch may still be read by kernels queued on any of the context's streams
@@ -293,24 +444,34 @@ int ensure_la(medgp_ctx *c, int nbatch, int nbmax, LaArgs *out) {
     int rc;
     if ((rc = grow(&c->d_la_part, &c->la_part_cap, need_part))) return rc;
     if ((rc = grow(&c->d_la_small, &c->la_small_cap, need_small))) return rc;
-    A.part = c->d_la_part;
-    A.ybuf = c->d_la_small;
-    A.xk2 = c->d_la_small + (size_t)nbatch * 64 * c->ldn;
-    A.pnx = A.xk2 + (size_t)nbatch * nring * 4096;
-    A.pnx2 = A.pnx + (size_t)nbatch * nring * 4096;
-    A.dterm = A.pnx2 + (size_t)nbatch * nring * 4096;
-    A.dsum = A.dterm + (size_t)nbatch * nring * 4096;
-    A.dpart = A.dsum + (size_t)nbatch * nring * 4096;
-    A.flag = (int *)(A.dpart + (size_t)nbatch * 2 * A.maxslice * 4096);
-    *out = A;
+    double *pp = c->d_la_part, *ps = c->d_la_small;
+    for (LaNeed &e : v) {
+        LaArgs A{};
+        const size_t nb = e.count;
+        A.nbmax = e.nbmax;
+        A.maxslice = (e.nbmax + LA_SLICE - 1) / LA_SLICE;
+        A.rows = 2 * e.nbmax + 1;
+        A.ring = 1;
+        A.part = pp;
+        A.ybuf = ps;
+        A.xk2 = ps + nb * 64 * e.ld;
+        A.pnx = A.xk2 + nb * nring * 4096;
+        A.pnx2 = A.pnx + nb * nring * 4096;
+        A.dterm = A.pnx2 + nb * nring * 4096;
+        A.dsum = A.dterm + nb * nring * 4096;
+        A.dpart = A.dsum + nb * nring * 4096;
+        A.flag = (int *)(A.dpart + nb * 2 * A.maxslice * 4096);
+        e.A = A;
+        pp += part_of(e); ps += small_of(e);
+    }
     return MEDGP_OK;
 }
 
-// one kernel chain for the batch entries described by L (possibly a shifted view of c->dev) on `stream`
-int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nbatch, int max_n, const double *theta_dev,
+// one kernel chain for the `nbatch` entries of the view L (a size class of the call) on `stream`; nt64 = 64-blocks of its largest entry,
+// entry_n = their sizes (host mirror), route = how they are factored, la = the look-ahead scratch (ROUTE_LA only)
+int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nbatch, int nt64, const double *theta_dev,
                      int flag_grad, bool need_inverse, int min_n, double *nlml_dev, double *grad_dev, int32_t *status_dev,
-                     bool store_ukk, const int *entry_n) {
-    const int nt64 = medgp_roundup(std::max(max_n, 1), 64) / 64;
+                     bool store_ukk, const int *entry_n, int route, const LaArgs *la_in) {
     { Launcher l(c, KID_PREP, stream); hipLaunchKernelGGL(k_prep, dim3(nbatch, 1 + (L.Q * L.ldn + PREP_CHUNK - 1) / PREP_CHUNK + ((theta_dev && L.kidx == 7) ? (L.Q * L.D * L.D + PREP_BCHUNK - 1) / PREP_BCHUNK : 0)), dim3(256), 0, stream, L, theta_dev, min_n); }
     auto launch_assemble = [&]() {
         Launcher l(c, KID_ASSEMBLE, stream);
@@ -333,25 +494,15 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
     };
     const bool inv = flag_grad || need_inverse;
     const int want_mode = inv ? 1 : (store_ukk ? 2 : 0);   // bit 0: U rows + alpha; 2: diagonal blocks U_kk only (k_predict)
-    // Few large patients: the multi-CU look-ahead schedule (kernels_cholinv_la.h) instead of one workgroup per patient.
-    // Measured on MI355X, round 4 (scratch/route_sweep.py -> profiles/r04_route_table.txt; factorisation ms per call, nlml + gradient,
-    // LA = look-ahead schedule, 44 / 84 = k_cholinv<4,4> / <8,4>; the same table at D = 2 and D = 24):
-    //   N=128: 44 wins at every batch size (0.069 vs LA 0.073 at 8 entries, 0.081 vs 0.112 at 256)
-    //   N=256: LA <= 96 entries (0.127 / 0.168 vs 44: 0.168 / 0.182 at 8 / 96), 44 from 128 on (0.185 vs LA 0.197)
-    //   N=384: LA <= 128 (0.390 vs 84: 0.395), 84 from 160 on (0.412 vs LA 0.473)
-    //   N=512: LA <= 96 (0.560 vs 0.683), tie at 128 (0.709 / 0.705), 84 from 160 on (0.712 vs 0.885)
-    //   N=768 / 1024: LA <= 128 (1.78 vs 1.86; 3.46 vs 3.69), 84 from 160 on (1.91 vs 2.19; 3.74 vs 4.34)
-    // The LA time grows linearly with the batch, the single-workgroup time is flat up to one patient per CU.  Rule: never for two
-    // blocks; up to 7/16 #CU entries (112) for three or four blocks; up to 9/16 #CU (144) from five blocks on.
-    const int la_max_batch = nt64 <= 2 ? 0 : (nt64 <= 4 ? (c->num_cu * 7) / 16 : (c->num_cu * 9) / 16);
-    const bool multi_cu = !c->use_v0 && !c->pin_route && (c->force_mc > 0 || (c->force_mc == 0 && nbatch <= la_max_batch));
+    // Few large patients: the multi-CU look-ahead schedule (kernels_cholinv_la.h) instead of one workgroup per patient; which classes
+    // of a call take it is decided in run_pipeline (route rule).
+    const bool multi_cu = route == ROUTE_LA;
     if (multi_cu) {
         // which entries the multi-CU schedule factors: more than one 64-block (host mirror of the patient sizes)
         bool any_small = false;
         for (int bb = 0; bb < nbatch; bb++) any_small = any_small || entry_n[bb] <= 64;
         {
-            LaArgs la{};
-            { int rc = ensure_la(c, nbatch, nt64, &la); if (rc) return rc; }
+            const LaArgs la = *la_in;
             launch_assemble();
             // entries of a single 64-block: one workgroup each (the same kernel, hence the same bits, as in any other call)
             if (any_small) { Launcher l(c, KID_CHOLINV, stream); hipLaunchKernelGGL((k_cholinv<8, 4, 1>), dim3(nbatch), dim3(512), 0, stream, L, want_mode); }
@@ -392,8 +543,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         // compiled ONCE for the tightest register budget among its callers -- with a <*,2> shape (four waves per SIMD, 128 VGPRs)
         // in the library it is held to 128 VGPRs and carries 182 scratch accesses on the serial path of EVERY shape (248 VGPRs and
         // 18 without; found when the legacy k_ci_panel caller that had masked this left the build: k_cholinv<4,4> 1.37 -> 1.48 ms).
-        const int shape = c->pin_route ? 84 : (c->cholinv_nw ? c->cholinv_nw : ((nbatch > c->num_cu || nt64 <= 4) ? 44 : 84));
-        if (shape == 44) hipLaunchKernelGGL((k_cholinv<4, 4, 0>), dim3(nbatch), dim3(256), 0, stream, L, want_mode);
+        if (route == ROUTE_WG44) hipLaunchKernelGGL((k_cholinv<4, 4, 0>), dim3(nbatch), dim3(256), 0, stream, L, want_mode);
         else hipLaunchKernelGGL((k_cholinv<8, 4, 0>), dim3(nbatch), dim3(512), 0, stream, L, want_mode);
     }
     int from_slab = 0;
@@ -445,46 +595,81 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
 }
 
 
-// view of the batch-indexed buffers starting at entry b0
-MedgpDev shifted_view(const MedgpDev &L, int b0) {
-    MedgpDev V = L;
-    const size_t ld = L.ldn, Q = L.Q, D = L.D;
-    V.bslot = L.bslot + b0;
-    V.hyp = L.hyp + (size_t)b0 * L.hyp_stride;
-    V.cs = L.cs + (size_t)b0 * Q * ld; V.sn = L.sn + (size_t)b0 * Q * ld;
-    V.Kmat = L.Kmat + (size_t)b0 * ld * ld; V.Linv = L.Linv + (size_t)b0 * ld * ld;
-    V.z = L.z + (size_t)b0 * ld; V.alpha = L.alpha + (size_t)b0 * ld; V.wdiag = L.wdiag + (size_t)b0 * ld;
-    V.epi_lp = L.epi_lp + (size_t)b0 * MEDGP_EPI_PARTS; V.epi_ticket = L.epi_ticket + b0;
-    V.scal = L.scal + (size_t)b0 * 4; V.status = L.status + b0; V.jit = L.jit + b0; V.bn = L.bn + b0; V.xk = L.xk + (size_t)b0 * 64 * 64;
-    V.S = L.S + (size_t)b0 * Q * D * D; V.SM = L.SM + (size_t)b0 * Q * D * D; V.SV = L.SV + (size_t)b0 * Q * D * D;
-    V.slab = L.slab + (size_t)b0 * L.slab_stride;
-    return V;
-}
-
-// The evaluation pipeline; everything is asynchronous on c->stream.  Optional (MEDGP_STREAMS=2): large batches split
-// in two halves on two auxiliary streams so that k_cholinv of one half co-runs with the VALU-heavy kernels of the
-// other half.  Measured on MI355X at the headline shape: no gain (98.9k vs 104.6k evals/s), so it is off by default.
+// The evaluation pipeline; everything is asynchronous and ordered on c->stream.  Every size class of the plan gets its own kernel
+// chain; with more than one class the chains run on auxiliary streams forked from / joined into c->stream, so that the workgroup-per-
+// patient launches of the small classes fill the CUs a look-ahead chain of the large ones leaves idle.
+//
+// Route rule.  Measured on MI355X, round 4 (scratch/route_sweep.py -> profiles/r04_route_table.txt; factorisation ms per call, nlml +
+// gradient, LA = look-ahead schedule, 44 / 84 = k_cholinv<4,4> / <8,4>; the same table at D = 2 and D = 24):
+//   N=128: 44 wins at every batch size (0.069 vs LA 0.073 at 8 entries, 0.081 vs 0.112 at 256)
+//   N=256: LA <= 96 entries (0.127 / 0.168 vs 44: 0.168 / 0.182 at 8 / 96), 44 from 128 on (0.185 vs LA 0.197)
+//   N=384: LA <= 128 (0.390 vs 84: 0.395), 84 from 160 on (0.412 vs LA 0.473)
+//   N=512: LA <= 96 (0.560 vs 0.683), tie at 128 (0.709 / 0.705), 84 from 160 on (0.712 vs 0.885)
+//   N=768 / 1024: LA <= 128 (1.78 vs 1.86; 3.46 vs 3.69), 84 from 160 on (1.91 vs 2.19; 3.74 vs 4.34)
+// The LA time grows linearly with the batch, the single-workgroup time is flat up to one patient per CU.  For a uniform call that gave:
+// never for two blocks; up to 7/16 #CU entries (112) for three or four blocks; up to 9/16 #CU (144) from five blocks on.  Round 5 states the
+// same rule per size CLASS of a ragged call: with t(nb) the one-workgroup cost model (wg_cost) and S the summed cost of the entries not
+// yet given to the look-ahead schedule, a class (largest first) takes the look-ahead schedule when  t(nb_max) * #CU * f >= S  (f = 7/16
+// or 9/16 as above) -- i.e. when one of its entries on one workgroup would stick out of the average load per CU of everything that is
+// left.  For a uniform call S = n t and the rule is the old one (n <= 112 / 144); in a ragged call the heavy tail is peeled off class by
+// class until the rest is balanced.
 int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, int flag_grad, bool need_inverse, int min_n,
                  double *nlml_dev, double *grad_dev, int32_t *status_dev, bool store_ukk = false) {
+    (void)max_n;
+    BatchPlan &P = c->plan;
+    { int rc = ensure_arena(c, P.need_mat, P.need_vec, P.need_tab, P.need_slab); if (rc) return rc; }
     c->last_has_inverse = flag_grad || need_inverse;
-    std::vector<int> ens(nbatch);   // n of every entry (host mirror)
-    for (int bb = 0; bb < nbatch; bb++) { const int es = c->h_bslot[bb]; ens[bb] = c->h_n[es >= c->max_slots ? es - c->max_slots : es]; }
-    // (never together with the multi-CU schedule: its look-ahead scratch is one per-context buffer, not one per stream)
-    const bool split = !c->use_v0 && c->nsplit >= 2 && c->force_mc <= 0 && nbatch >= 2 * c->num_cu && c->aux[0] && c->aux[1];
-    if (!split) return run_pipeline_one(c, c->stream, c->dev, nbatch, max_n, theta_dev, flag_grad, need_inverse, min_n, nlml_dev, grad_dev, status_dev, store_ukk, ens.data());
-    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-    const int h = (nbatch / 2 + 1) & ~1;   // even: keeps the (b & 1) wave mirroring of k_cholinv consistent
-    const int b0[2] = {0, h}, nb[2] = {h, nbatch - h};
-    for (int i = 0; i < 2; i++) {
-        HIPCHK(c, hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
-        MedgpDev V = shifted_view(c->dev, b0[i]);
-        int rc = run_pipeline_one(c, c->aux[i], V, nb[i], max_n, theta_dev + (size_t)b0[i] * c->H, flag_grad, need_inverse, min_n,
-                                  nlml_dev ? nlml_dev + b0[i] : nullptr, grad_dev ? grad_dev + (size_t)b0[i] * c->H : nullptr,
-                                  status_dev ? status_dev + b0[i] : nullptr, store_ukk, ens.data() + b0[i]);
-        if (rc) return rc;
-        HIPCHK(c, hipEventRecord(c->ev_join[i], c->aux[i]));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[i], 0));
+    long long S = 0;
+    for (const SizeClass &k : P.cls) S += k.tsum;
+    std::vector<LaNeed> las;
+    std::vector<int> la_of(P.cls.size(), -1);
+    for (size_t i = 0; i < P.cls.size(); i++) {
+        SizeClass &k = P.cls[i];
+        bool la = false;
+        if (!c->use_v0 && !c->pin_route && k.nbmax >= 2) {
+            if (c->force_mc > 0) la = true;   // (forced, A-B and tests: also for two blocks)
+            else if (c->force_mc == 0 && k.nbmax >= 3 && !c->no_classes) la = wg_cost(k.nbmax) * c->num_cu * (k.nbmax <= 4 ? 7 : 9) >= 16 * S;
+            else if (c->force_mc == 0 && k.nbmax >= 3) la = k.count <= (c->num_cu * (k.nbmax <= 4 ? 7 : 9)) / 16;   // rounds 1-4: by entry count alone
+        }
+        if (la) {
+            k.route = ROUTE_LA;
+            S -= k.tsum;
+            la_of[i] = (int)las.size();
+            las.push_back({k.count, k.nbmax, k.ld, LaArgs{}});
+        } else {
+            // more patients than CUs: 4-wave workgroups, two per CU (the serial diagonal phase of one overlaps the MFMA phase of the
+            // other).  At most one patient per CU: 8 waves (8 block slots per pass) once a step has more than 4 row blocks, else the
+            // 4-wave shape, whose 4 slots already cover every block of n <= 256 (measured, 256 patients x N=256, D=2: <4,4> 0.211 ms,
+            // <8,4> 0.232 ms -- half of its 8 slots idle).
+            const int shape = c->pin_route ? 84 : (c->cholinv_nw ? c->cholinv_nw : ((k.count > c->num_cu || k.nbmax <= 4) ? 44 : 84));
+            k.route = shape == 44 ? ROUTE_WG44 : ROUTE_WG84;
+        }
     }
+    if (!las.empty()) { int rc = ensure_la(c, las); if (rc) return rc; }
+    const bool fork = P.cls.size() > 1 && c->class_streams > 0 && c->aux[0];
+    if (fork) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    const int nstr = std::min(c->class_streams, kAuxStreams);
+    bool used[kAuxStreams] = {false, false, false, false};
+    for (size_t i = 0; i < P.cls.size(); i++) {
+        const SizeClass &k = P.cls[i];
+        hipStream_t st = c->stream;
+        int ai = -1;
+        if (fork && i > 0) {   // class 0 (the largest entries) stays on the call's stream
+            ai = (int)((i - 1) % nstr);
+            st = c->aux[ai];
+            if (!used[ai]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); used[ai] = true; }
+        }
+        const MedgpDev V = class_view(c, k);
+        int rc = run_pipeline_one(c, st, V, k.count, k.nbmax, theta_dev, flag_grad, need_inverse, min_n, nlml_dev, grad_dev, status_dev, store_ukk,
+                                  P.en.data() + k.b0, k.route, la_of[i] >= 0 ? &las[la_of[i]].A : nullptr);
+        if (rc) return rc;
+    }
+    if (fork)
+        for (int ai = 0; ai < nstr; ai++)
+            if (used[ai]) {
+                HIPCHK(c, hipEventRecord(c->ev_join[ai], c->aux[ai]));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[ai], 0));
+            }
     return MEDGP_OK;
 }
 
@@ -528,10 +713,11 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     { const char *e = getenv("MEDGP_LA_PARK"); if (e) c->la_park = atoi(e); }
     { const char *e = getenv("MEDGP_LA_PARK_MAXBATCH"); if (e) c->la_park_maxbatch = atoi(e); }
     { const char *e = getenv("MEDGP_MULTI_CU"); c->force_mc = e ? atoi(e) : 0; }
-    { const char *e = getenv("MEDGP_STREAMS"); c->nsplit = e ? atoi(e) : 1; }
+    { const char *e = getenv("MEDGP_CLASS_STREAMS"); if (e) c->class_streams = std::max(0, std::min(kAuxStreams, atoi(e))); }
+    { const char *e = getenv("MEDGP_NO_CLASSES"); c->no_classes = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_WGRAD_DEEP"); c->wgrad_deep = e ? std::max(1, atoi(e)) : -1; }
     { const char *e = getenv("MEDGP_DEBUG_FAIL_ATTEMPTS"); c->dbg_fail = e ? atoi(e) : 0; }
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < kAuxStreams; i++) {
         (void)hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
         (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
     }
@@ -548,7 +734,7 @@ void medgp_destroy(medgp_ctx *c) {
     for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     free_all(c);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < kAuxStreams; i++) {
         if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
@@ -617,6 +803,7 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     if ((rc = dalloc(c, &c->d_prior, S * H))) return rc;
     if ((rc = dalloc(c, &c->d_prior_on, S))) return rc;
     if ((rc = dalloc(c, &c->d_bslot, B))) return rc;
+    if ((rc = dalloc(c, &c->d_bpos, B))) return rc;
     if ((rc = dalloc(c, &c->d_status, B))) return rc;
     if ((rc = dalloc(c, &c->d_jit, B))) return rc;
     if ((rc = dalloc(c, &c->d_bn, B))) return rc;
@@ -632,26 +819,23 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     c->d_prior_stage = nullptr; c->d_prior_slots = nullptr; c->prior_stage_rows = 0;   // freed by free_all above
     MedgpDev &L = c->dev;
     L.kidx = c->kidx; L.Q = c->Q; L.D = c->D; L.R = c->R; L.H = c->H; L.nlik = c->nlik;
-    L.ldn = ldn; L.max_slots = max_slots; L.max_batch = max_batch;
+    L.ldn = ldn; L.pld = ldn; L.max_slots = max_slots; L.max_batch = max_batch;
+    L.bpos = nullptr;
     L.hyp_stride = (int)(D + Q * D * D + 2 * Q);
     L.pi = c->pi;
     L.dbg_fail = c->dbg_fail;
-    double *hyp, *cs, *sn, *Kmat, *Linv, *z, *alpha, *scal, *Sb, *SMb, *SVb, *slab, *wdiag;
+    double *hyp, *scal, *Sb, *SMb, *SVb;
     L.slab_R = ldn / 16 + (int)D;
     L.slab_C = ldn / 64 + (int)D;
     L.slab_stride = (size_t)3 * Q * L.slab_R * L.slab_C;
-    if ((rc = dalloc(c, &slab, B * L.slab_stride))) return rc;
-    if ((rc = dalloc(c, &wdiag, B * ldn))) return rc;
+    c->full_mat = B * ldn * ldn; c->full_vec = B * ldn; c->full_tab = B * Q * ldn; c->full_slab = B * L.slab_stride;
+    c->cap_mat = c->cap_vec = c->cap_tab = c->cap_slab = 0;
+    L.Kmat = L.Linv = L.z = L.alpha = L.wdiag = L.cs = L.sn = L.slab = nullptr;
+    if (2 * c->full_mat * sizeof(double) <= kArenaEager && (rc = ensure_arena(c, c->full_mat, c->full_vec, c->full_tab, c->full_slab))) return rc;
     double *xk;
     if ((rc = dalloc(c, &xk, B * 64 * 64))) return rc;
     L.xk = xk; L.jit = c->d_jit; L.bn = c->d_bn;
     if ((rc = dalloc(c, &hyp, B * L.hyp_stride))) return rc;
-    if ((rc = dalloc(c, &cs, B * Q * ldn))) return rc;
-    if ((rc = dalloc(c, &sn, B * Q * ldn))) return rc;
-    if ((rc = dalloc(c, &Kmat, B * ldn * ldn))) return rc;
-    if ((rc = dalloc(c, &Linv, B * ldn * ldn))) return rc;
-    if ((rc = dalloc(c, &z, B * ldn))) return rc;
-    if ((rc = dalloc(c, &alpha, B * ldn))) return rc;
     if ((rc = dalloc(c, &scal, B * 4))) return rc;
     if ((rc = dalloc(c, &L.epi_lp, B * MEDGP_EPI_PARTS))) return rc;
     if ((rc = dalloc(c, &L.epi_ticket, B))) return rc;
@@ -660,9 +844,9 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     if ((rc = dalloc(c, &SMb, B * Q * D * D))) return rc;
     if ((rc = dalloc(c, &SVb, B * Q * D * D))) return rc;
     L.pn = c->d_pn; L.pt = c->d_pt; L.py = c->d_py; L.pmeta = c->d_pmeta; L.pseg = c->d_pseg;
-    L.proff = c->d_proff; L.pcoff = c->d_pcoff; L.slab = slab; L.wdiag = wdiag;
+    L.proff = c->d_proff; L.pcoff = c->d_pcoff;
     L.prior = c->d_prior; L.prior_on = c->d_prior_on; L.bslot = c->d_bslot;
-    L.hyp = hyp; L.cs = cs; L.sn = sn; L.Kmat = Kmat; L.Linv = Linv; L.z = z; L.alpha = alpha; L.scal = scal;
+    L.hyp = hyp; L.scal = scal;
     L.status = c->d_status; L.S = Sb; L.SM = SMb; L.SV = SVb;
     HIPCHK(c, hipMemsetAsync(c->d_prior_on, 0, S, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_pn, 0, 2 * S * sizeof(int), c->stream));
@@ -672,6 +856,7 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     c->h_perm_identity.assign(max_slots, 1);
     c->h_bslot.assign(max_batch, -1);
     c->last_nbatch = 0;
+    c->plan = BatchPlan{};
     c->last_has_inverse = false;
     c->pred_cap = 0;
     c->d_stage = nullptr;   // freed by free_all above
@@ -899,7 +1084,7 @@ int medgp_nlml_grad_device(medgp_ctx *c, int nbatch, const int32_t *slots, const
     int max_n = 0, rc;
     // factor wanted but no gradient: patients that were not uploaded grouped by output are evaluated in the CALLER's order,
     // so that L^-1 is the factor the reference would hand to GP_Regression::predict (ref: core/gp_regression.cpp:181-196)
-    if ((rc = set_batch(c, nbatch, slots, &max_n, keep && !grad))) return rc;
+    if ((rc = set_batch(c, nbatch, slots, &max_n, keep && !grad, true))) return rc;
     return run_pipeline(c, nbatch, max_n, theta_dev, grad, keep, 3, nlml_dev, grad_dev, status_dev);
 }
 
@@ -1000,12 +1185,14 @@ int medgp_get_factor(medgp_ctx *c, int b, float *alpha, float *linv, float *beta
         return fail(c, MEDGP_ERR_ARG, "no factor available: the last call formed neither gradients nor the factor "
                                       "(pass MEDGP_FLAG_GRAD or MEDGP_FLAG_KEEP_FACTOR to medgp_nlml_grad)");
     HIPCHK(c, hipSetDevice(c->device));
-    const int S = c->max_slots, ld = c->ldn;
+    const int S = c->max_slots;
+    const MedgpDev E = entry_view(c, b);   // the entry's rows of the batch buffers (its size class's view, shifted)
+    const int ld = E.ldn;
     int eff = c->h_bslot[b];
     const int slot = eff >= S ? eff - S : eff, n = c->h_n[slot];
     const std::vector<int> &perm = c->h_perm[slot];
     int st = 0;
-    HIPCHK(c, hipMemcpyAsync(&st, c->d_status + b, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&st, E.status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (st < 0) return fail(c, MEDGP_ERR_ARG, "batch entry %d failed (status %d); no factor available", b, st);
     if (linv && eff < S && !c->h_perm_identity[slot]) {
@@ -1013,15 +1200,22 @@ int medgp_get_factor(medgp_ctx *c, int b, float *alpha, float *linv, float *beta
         // one entry from the caller-order copy of the patient (same hyper block; tables, Gram, factor and inverse redone).
         const int shadow = slot + S;
         HIPCHK(c, hipMemcpyAsync(c->d_one_slot, &shadow, sizeof(int), hipMemcpyHostToDevice, c->stream));
-        MedgpDev V = shifted_view(c->dev, b);
+        MedgpDev V = E;
         V.bslot = c->d_one_slot;
+        V.bpos = nullptr;
         const bool prof = c->profiling;
         c->profiling = false;   // not part of the evaluation being measured
-        int rc = run_pipeline_one(c, c->stream, V, 1, n, nullptr, 0, true, 1, nullptr, nullptr, nullptr, false, &n);
+        // (one entry: the route rule of run_pipeline for a uniform call of one)
+        const int nb1 = blocks64(n);
+        const bool la1 = !c->use_v0 && !c->pin_route && nb1 >= 2 && (c->force_mc > 0 || (c->force_mc == 0 && nb1 >= 3));
+        std::vector<LaNeed> las;
+        if (la1) { las.push_back({1, nb1, ld, LaArgs{}}); int rcl = ensure_la(c, las); if (rcl) return rcl; }
+        const int route1 = la1 ? ROUTE_LA : (c->pin_route ? ROUTE_WG84 : (c->cholinv_nw ? (c->cholinv_nw == 44 ? ROUTE_WG44 : ROUTE_WG84) : (nb1 <= 4 ? ROUTE_WG44 : ROUTE_WG84)));
+        int rc = run_pipeline_one(c, c->stream, V, 1, nb1, nullptr, 0, true, 1, nullptr, nullptr, nullptr, false, &n, route1, la1 ? &las[0].A : nullptr);
         c->profiling = prof;
         if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->d_bslot + b, c->d_one_slot, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&st, c->d_status + b, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync((int *)E.bslot, c->d_one_slot, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&st, E.status, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->h_bslot[b] = eff = shadow;
         if (st < 0) return fail(c, MEDGP_ERR_ARG, "batch entry %d: the factorisation in the caller's order failed (status %d)", b, st);
@@ -1029,17 +1223,17 @@ int medgp_get_factor(medgp_ctx *c, int b, float *alpha, float *linv, float *beta
     const bool caller_order = eff >= S || c->h_perm_identity[slot];
     if (alpha) {
         std::vector<double> ha(n);
-        HIPCHK(c, hipMemcpy(ha.data(), c->dev.alpha + (size_t)b * ld, sizeof(double) * n, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(ha.data(), E.alpha, sizeof(double) * n, hipMemcpyDeviceToHost));
         for (int i = 0; i < n; i++) alpha[caller_order ? i : perm[i]] = (float)ha[i];
     }
     if (beta) {
         double sc[4];
-        HIPCHK(c, hipMemcpy(sc, c->dev.scal + (size_t)b * 4, sizeof(sc), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(sc, E.scal, sizeof(sc), hipMemcpyDeviceToHost));
         *beta = (float)sc[1];
     }
     if (linv) {
         const char *hp = nullptr;
-        int rc2 = d2h_pinned(c, c->dev.Linv + (size_t)b * ld * ld, sizeof(double) * n * ld, &hp);
+        int rc2 = d2h_pinned(c, E.Linv, sizeof(double) * n * ld, &hp);
         if (rc2) return rc2;
         const double *hx = (const double *)hp;
         for (int i = 0; i < n; i++)
@@ -1166,6 +1360,17 @@ int medgp_pin_route(medgp_ctx *c, int pinned) {
     if (!c) return MEDGP_ERR_ARG;
     c->pin_route = pinned ? 1 : 0;
     return MEDGP_OK;
+}
+
+int medgp_last_plan(const medgp_ctx *c, int max_classes, int32_t *count, int32_t *blocks, int32_t *route) {
+    if (!c) return MEDGP_ERR_ARG;
+    const int nc = (int)c->plan.cls.size();
+    for (int i = 0; i < nc && i < max_classes; i++) {
+        if (count) count[i] = c->plan.cls[i].count;
+        if (blocks) blocks[i] = c->plan.cls[i].nbmax;
+        if (route) route[i] = c->plan.cls[i].route;
+    }
+    return nc;
 }
 
 int medgp_fit_predict(medgp_ctx *c, int slot, const double *theta, int nstar, const int32_t *meta2, const float *t2,

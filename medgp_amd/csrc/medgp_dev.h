@@ -26,7 +26,8 @@ struct MedgpPrior {          // one hyper of one slot
 struct MedgpDev {
     // family
     int kidx, Q, D, R, H, nlik;
-    int ldn, max_slots, max_batch;
+    int ldn, max_slots, max_batch;   // ldn: leading dimension of THIS VIEW's batch buffers (a size class of the call: the class's largest n rounded up to 64)
+    int pld;                 // row stride of the patient arrays pt / py / pmeta (the context's max_n rounded up to 64)
     int hyp_stride;          // doubles per batch entry in `hyp`
     double pi;
     int dbg_fail;            // test hook (MEDGP_DEBUG_FAIL_ATTEMPTS=k): the first k factorisation attempts of every problem are
@@ -42,6 +43,8 @@ struct MedgpDev {
     const uint8_t *prior_on; // [slot]
     // batch
     const int *bslot;        // [nbatch]
+    const int *bpos;         // [nbatch] position of the entry in the CALLER's batch (theta, nlml, gradient, status rows), or null = identity:
+                             // a call's entries are ordered by size internally (size classes are contiguous, medgp_capi.hip: BatchPlan)
     double *hyp;             // [batch][hyp_stride]: sig2[D] | B[Q*D*D] | w[Q] | c[Q]
     double *cs, *sn;         // [batch][Q][ldn]
     double *Kmat, *Linv;     // [batch][ldn*ldn]

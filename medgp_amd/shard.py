@@ -29,3 +29,10 @@ def lpt_partition(ns, world_size, Q=5):
 def weak_shard(P_per_rank, rank):
     """Weak scaling: every rank owns P_per_rank patients; global patient ids are contiguous."""
     return np.arange(rank * P_per_rank, (rank + 1) * P_per_rank, dtype=np.int64)
+
+
+def exit_status(returncode):
+    """Exit status of a child as a NON-NEGATIVE int that survives max(): subprocess reports a child killed by signal s as -s
+    (a HIP fault -> SIGABRT = -6, the OOM killer = -9), which would lose against the 0 of the healthy ranks in
+    all_reduce(MAX) and in `rc = max(rc, ...)`.  The shell convention: 128 + s."""
+    return returncode if returncode >= 0 else 128 - returncode

@@ -104,3 +104,21 @@ def hier_gamma_prior(Q, D, R, beta_lam=0.01):
     ex[k0:] = 1
     p1[k0:] = np.float32(beta_lam)
     return flag, typ, ex, p0, p1
+
+
+def ragged_sizes(seed, P, median=250.0, sigma=1.0, nmin=8, nmax=6000):
+    """Observation counts of a heavy-tailed cohort: log-normal around `median` (real cohorts are: the reference's job generator
+    buckets patients by N and gives the large ones more resources, ref: scripts/slurm_della.json:6-62,
+    medgpc/util/run_exp_generator.py:213-260).  seed 0, P = 300: median 263, eight patients above N = 1400, the largest 5832."""
+    g = np.random.Generator(np.random.Philox(key=[seed, 77]))
+    return np.clip(np.exp(np.log(median) + sigma * g.standard_normal(P)), nmin, nmax).astype(np.int64)
+
+
+def ragged_cohort(seed, P, D, kernel_index=7, Q=5, R=None, **kw):
+    """Patients of ragged_sizes(seed, P) + one theta each: list of (meta, t, y), theta [P, H], sizes [P]."""
+    if R is None:
+        R = min(8, D)
+    ns = ragged_sizes(seed, P, **kw)
+    pts = [patient(seed + 17, p, D, int(ns[p])) for p in range(P)]
+    th = np.stack([theta(seed + 17, p, kernel_index, Q, D, R) for p in range(P)])
+    return pts, th, ns

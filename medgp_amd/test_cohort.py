@@ -22,6 +22,8 @@ import sys
 
 import numpy as np
 
+from . import shard
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_EXE = os.path.join(HERE, "host", "medgp_test")
 
@@ -103,7 +105,7 @@ def main(argv=None):
         if args.max_batch > 0:
             cmd += ["--max-batch", str(args.max_batch)]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        rc = r.returncode
+        rc = shard.exit_status(r.returncode)
         with open(os.path.join(cfg["exp_test_dir"], f"test_fold{args.fold}_rank{rank}.log"), "w") as f:
             f.write(r.stdout)
     if world > 1:
@@ -113,9 +115,9 @@ def main(argv=None):
         import torch.distributed as dist
         backend = args.backend or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(device)      # (the device the trainer ran on: local_rank % ndev, ranks may share GPUs)
         dist.init_process_group(backend, timeout=datetime.timedelta(hours=args.timeout_hours))
-        dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+        dev = torch.device("cuda", device) if dist.get_backend() == "nccl" else torch.device("cpu")
         flag = torch.tensor([rc], dtype=torch.int64, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         rc = int(flag.item())

@@ -113,7 +113,7 @@ def main(argv=None):
                             "--max-batch", str(args.max_batch)] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         with open(os.path.join(cfg["exp_train_dir"], f"train_{tag}.log"), "w") as f:
             f.write(r.stdout)
-        return r.returncode
+        return shard.exit_status(r.returncode)
 
     rc = 0
     mine = []          # global indices of the patients this rank trained
@@ -150,9 +150,9 @@ def main(argv=None):
         import torch.distributed as dist
         backend = args.backend or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(device)      # (the device the trainer ran on: local_rank % ndev, ranks may share GPUs)
         dist.init_process_group(backend, timeout=datetime.timedelta(hours=args.timeout_hours))
-        dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+        dev = torch.device("cuda", device) if dist.get_backend() == "nccl" else torch.device("cpu")
         flag = torch.tensor([rc], dtype=torch.int64, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         rc = int(flag.item())
