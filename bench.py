@@ -89,6 +89,20 @@ def pmc_traffic(kernel, P, N):
     return None, dict(prov, status="kernel not in the summary")
 
 
+def check_ranks(seen, world, backend):
+    """None, or what is wrong with the set of ranks that took part: under nccl (one rank per GPU) the (host, uuid) pairs must be
+    pairwise distinct and every rank must have reported."""
+    if len(seen) != world or any(r is None for r in seen):
+        return f"{sum(r is not None for r in seen)} of {world} ranks reported"
+    if sorted(r["rank"] for r in seen) != list(range(world)):
+        return "rank ids are not 0 .. %d: %s" % (world - 1, [r["rank"] for r in seen])
+    if backend == "nccl":
+        ids = [(r["host"], r["uuid"] or f"device{r['device']}") for r in seen]
+        if len(set(ids)) != world:
+            return "ranks share a GPU under the nccl backend: " + ", ".join(f"rank {r['rank']} -> {r['host']}:{r['device']} ({r['uuid']})" for r in seen)
+    return None
+
+
 def aggregate_time(t_local, world):
     """max over ranks of the local wall time (the driver's contract)."""
     if world <= 1:
@@ -448,6 +462,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --patients per GPU (default); strong: the fixed --cohort (BASELINE config 4: 4096 patients) LPT-sharded over the ranks")
     ap.add_argument("--cohort", type=int, default=4096, help="cohort size of --scaling strong")
+    ap.add_argument("--backend", choices=("auto", "nccl", "gloo"), default="auto",
+                    help="process-group backend for N > 1: auto = nccl (RCCL) with one rank per GPU, gloo when ranks share GPUs")
     ap.add_argument("--dump-results", default=None, help="write this rank's (global patient ids, nlml, gradient row sums) to <path>.rank<r>.npz")
     args = ap.parse_args()
 
@@ -461,10 +477,13 @@ def main():
     ndev = torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
-        if ndev >= world:   # the driver's case: one rank per GPU, RCCL over xGMI
+        backend = args.backend if args.backend != "auto" else ("nccl" if ndev >= world else "gloo")
+        if backend == "nccl":   # the driver's case: one rank per GPU, RCCL over xGMI
+            if ndev < world:
+                sys.exit(f"bench.py: --backend nccl needs one GPU per rank ({world} ranks, {ndev} GPUs visible)")
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:               # more ranks than GPUs (testing the multi-rank path on a 1-GPU box): share devices, gloo
+        else:                   # gloo: also with more ranks than GPUs (testing the multi-rank path on a 1-GPU box): ranks share devices
             local_rank = local_rank % max(ndev, 1)
             torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo")
@@ -562,7 +581,7 @@ def main():
     # who actually ran: (rank, device index, device name, uuid, host) of every rank, gathered once outside the timed region
     props = torch.cuda.get_device_properties(local_rank)
     me = {"rank": rank, "device": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
-          "host": os.uname().nodename, "patients": int(P)}
+          "host": os.uname().nodename, "patients": int(P), "ms_per_step": 1e3 * t_local / max(args.steps, 1)}
     if world > 1:
         import torch.distributed as dist
         seen = [None] * world
@@ -570,6 +589,16 @@ def main():
         backend = dist.get_backend()
     else:
         seen, backend = [me], "none"
+    # One rank per GPU is what the scaling numbers mean: under nccl every rank must sit on a device of its own.  Two ranks on one
+    # device would still produce a line (half the per-rank rate each) -- refuse instead of reporting it.
+    problem = check_ranks(seen, world, backend)
+    if problem:
+        if rank == 0:
+            print("bench.py: " + problem, file=sys.stderr, flush=True)
+        ctx.close()
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(3)
 
     if rank == 0:
         total_patients = sum(r["patients"] for r in seen)
@@ -592,8 +621,10 @@ def main():
                      "kernel_ms_per_step": {k: round(v[0] / n_split, 4) for k, v in prof_all.items() if v[1] > 0},
                      "kernel_ms_per_step_source": "%d untimed steps behind the timed region, events around every launch; avg_launch_ms: live over the timed region" % n_split})
         f_alg = N ** 3 + 6 * N * N + 80 * Q * N * (N + 1) / 2
+        rank_ms = [r["ms_per_step"] for r in seen]
         extra = {
             "ranks_seen": seen, "backend": backend,
+            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "mean": sum(rank_ms) / len(rank_ms)},
             "roofline": roof,
             "end_to_end": {"flop_per_eval": f_alg, "tflops": f_alg * value / world / 1e12,
                            "frac_fp64_peak": f_alg * value / world / 1e12 / FP64_PEAK_TFLOPS},

@@ -204,7 +204,41 @@ def ref_config_files():
     print("ref_cfg/PT_INR/kernel/fold0: gmm_mode_param.bin, gmm_mode_mixture_num.txt")
 
 
+def ref_feature_roundtrip():
+    """The INPUT side of the file surface: per-patient feature<idx>.txt files as medgp_amd/synth_experiment.py writes them (count, then
+    t / v pairs, README.md:64-72), parsed here by the reference's own reader binaryIO.load_ts_data (medgpc/util/binaryIO.py:38-43).
+    The files and what the reference read from them are committed (tests/golden/ref_cfg/feature_rt); tests/test_host_files.py holds
+    the C++ loader (ref: dataio/c_experiment.cpp:254-309) to them.  Three patients: 13, 40 and 2 observations over two features (the
+    last one leaves feature 19 with a single observation)."""
+    import importlib.util
+    import shutil
+    spec = importlib.util.spec_from_file_location("ref_binaryIO", "/root/reference/medgpc/util/binaryIO.py")
+    bio = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bio)
+    from medgp_amd.synth_experiment import make_experiment
+    top = "tests/golden/ref_cfg/feature_rt"
+    cwd = os.getcwd()
+    os.chdir(ROOT)                       # relative paths in exp_setup.json: the CPU tests run host_logic_test from the repository root
+    try:
+        shutil.rmtree(top, ignore_errors=True)
+        pans = ["R001", "R002", "R003"]
+        ex = make_experiment(top, pans, D=2, Q=3, R=2, N=[13, 40, 2], feature_index=(18, 19), seed=11)
+        out = {}
+        for pan in pans:
+            for fi in ex["feature_index"]:
+                t, v = bio.load_ts_data(os.path.join(ex["dirs"]["data"], pan, f"feature{fi}.txt"))
+                out[f"{pan}_{fi}_t"] = np.atleast_1d(t)
+                out[f"{pan}_{fi}_v"] = np.atleast_1d(v)
+        out["stats"] = np.array(ex["stats"])
+        np.savez(os.path.join(top, "parsed_by_reference.npz"), **out)
+        for d in ("train", "test", "kernel"):
+            shutil.rmtree(os.path.join(top, d), ignore_errors=True)     # empty directories: nothing to commit
+        print("ref_cfg/feature_rt:", {k: v.shape for k, v in out.items()})
+    finally:
+        os.chdir(cwd)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["appendix_a", "fastkernel", "fastkernel_gram", "fastkernel_univariate", "config5", "ref_config_files"]
+    which = sys.argv[1:] or ["appendix_a", "fastkernel", "fastkernel_gram", "fastkernel_univariate", "config5", "ref_config_files", "ref_feature_roundtrip"]
     for w in which:
         globals()[w]()

@@ -62,3 +62,24 @@ def test_two_ranks_on_one_gpu_match_one_rank(tmp_path, mode):
     for g in r1:
         assert r1[g][2] == r2[g][2] == 0
         assert r1[g][0] == r2[g][0] and r1[g][1] == r2[g][1], (g, r1[g], r2[g])   # same bits whichever rank / batch evaluated the patient
+    # round 5: the line shows every rank's own time (an imbalance is visible), and the whole-job time is the slowest rank's
+    ms = [r["ms_per_step"] for r in two["ranks_seen"]]
+    assert two["rank_ms_per_step"]["min"] == min(ms) and two["rank_ms_per_step"]["max"] == max(ms)
+    assert max(ms) <= two["ms_per_step"] * 1.0001 and min(ms) > 0
+
+
+def test_backend_switch_and_nccl_refuses_shared_gpus(tmp_path):
+    """--backend gloo forces the CPU process group; --backend nccl with two ranks on this one-GPU box must FAIL LOUDLY (exit code,
+    message) instead of quietly timing two ranks on one device."""
+    import torch
+    two, _ = _run(2, ["--patients", "8", "--backend", "gloo"], str(tmp_path / "g"))
+    assert two["backend"] == "gloo"
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--patients", "8", "--backend", "nccl"] + COMMON
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert "needs one GPU per rank" in r.stderr + r.stdout
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

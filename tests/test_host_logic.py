@@ -147,3 +147,22 @@ def test_test_cohort_launcher_cost_model_and_gloo_run(tmp_path):
         if want_rc == 0:
             for p in pans:
                 assert open(os.path.join(ex["dirs"]["test"], f"test_mean_w_update_flag_{p}.txt")).read() == "1\n"
+
+
+def test_bench_refuses_ranks_that_share_a_gpu_under_nccl():
+    """bench.check_ranks: the first real 8-GPU run must fail loudly, not quietly, if two ranks land on one device."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    mk = lambda r, dev, uuid: {"rank": r, "device": dev, "name": "x", "uuid": uuid, "host": "h", "patients": 4, "ms_per_step": 1.0}
+    ok = [mk(r, r, f"u{r}") for r in range(8)]
+    assert bench.check_ranks(ok, 8, "nccl") is None
+    dup = ok[:7] + [mk(7, 6, "u6")]
+    assert "share a GPU" in bench.check_ranks(dup, 8, "nccl")
+    assert bench.check_ranks(dup, 8, "gloo") is None                       # the CPU stand-in shares devices by design
+    assert "of 8 ranks reported" in bench.check_ranks(ok[:7] + [None], 8, "nccl")
+    assert "rank ids" in bench.check_ranks(ok[:7] + [mk(3, 7, "u7")], 8, "nccl")
+    nouuid = [mk(r, r, "") for r in range(2)]                             # a torch without the uuid property: device index stands in
+    assert bench.check_ranks(nouuid, 2, "nccl") is None
+    assert "share a GPU" in bench.check_ranks([mk(0, 0, ""), mk(1, 0, "")], 2, "nccl")

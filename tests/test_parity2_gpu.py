@@ -401,3 +401,72 @@ def test_beyond_baseline_sizes_the_two_routes_agree(monkeypatch):
     assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0])
     gs = np.abs(b[1]).max()
     assert np.max(np.abs(a[1] - b[1]) / np.maximum(np.abs(b[1]), 1e-3 * gs)) <= 1e-9
+
+
+def test_config4_full_one_call_of_4096_vs_oracle():
+    """BASELINE config 4 as it is named: ONE call of 4096 evaluations at N=512, D=24 (16 passes of workgroups on 256 CUs, 147 k
+    k_wgrad workgroups) -- the launch shape bench.py's `config4_full` leg times.  32 entries against the oracle: the first and the
+    last entry of passes of 512 workgroup slots, the positions either side of an XCD group of eight, and a few in between."""
+    D, N, Q, R, P, seed = 24, 512, 5, 8, 4096, 2024
+    H = synth.num_hyp(7, Q, D, R)
+    nu = 64                                              # distinct patients / hyper vectors, replicated over the 4096 slots
+    pts, thu = synth.cohort(seed, nu, D, N, Q=Q, R=R)
+    ctx = medgp_amd.Context(7, Q, D, R)
+    ctx.reserve(P, N, P)
+    # entry s holds patient (s * 37) % nu and hyper vector (s * 11 + s // nu) % nu: neighbours differ, every pair occurs
+    pid = (np.arange(P) * 37) % nu
+    tid = (np.arange(P) * 11 + np.arange(P) // nu) % nu
+    ctx.set_patients(np.arange(P), [pts[i] for i in pid])
+    ctx.set_prior(-1, *synth.hier_gamma_prior(Q, D, R, 0.01))
+    th = thu[tid]
+    nlml, grad, st = ctx.nlml_grad(np.arange(P), th, True)
+    assert np.all(st == 0) and np.all(np.isfinite(nlml)) and np.all(np.isfinite(grad))
+    assert grad.shape == (P, H)
+    pr = O.Prior.hier_gamma(Q, D, R, 0.01, 0.01)
+    sample = sorted({0, 1, 7, 8, 255, 256, 511, 512, 513, 1023, 1024, 1535, 1536, 2047, 2048, 2049, 2559, 2560, 3071, 3072, 3583, 3584,
+                     4087, 4088, 4094, 4095, 777, 1291, 1999, 2817, 3333, 3901})
+    assert len(sample) == 32
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        refs = list(ex.map(lambda s: O.nlml_grad(7, Q, D, R, *pts[pid[s]], th[s], prior=pr, nthreads=1), sample))
+    for s, ref in zip(sample, refs):
+        assert ref["status"] == 0
+        assert_parity(nlml[s], grad[s], ref, f"s{s}")
+    # equal (patient, theta) pairs anywhere in the call give equal bits
+    key = pid.astype(np.int64) * nu + tid
+    first = {}
+    for s in range(P):
+        f = first.setdefault(int(key[s]), s)
+        if f != s:
+            assert nlml[s] == nlml[f] and np.array_equal(grad[s], grad[f]), (s, f)
+    ctx.close()
+
+
+@pytest.mark.parametrize("D,Q,R,ns", [(128, 2, 3, [300, 140, 9]), (256, 2, 2, [520, 256]), (256, 1, 1, [3, 70])])
+def test_many_outputs_vs_oracle(D, Q, R, ns):
+    """Up to the library's limit of outputs per context (MEDGP_MAX_D = 256, medgp_dev.h; the reference's D is a free key of the
+    kernel parameter list, ref: kernel/c_kernel_LMC_SM.cpp:51-70): most outputs have one observation or none, the per-output
+    offset tables of the slab sums and the epilogue's D-term dot products run at their full length."""
+    P = len(ns)
+    pts = [synth.patient(77, p, D, n) for p, n in enumerate(ns)]
+    th = np.stack([synth.theta(77, p, 7, Q, D, R, sparse_frac=0.2) for p in range(P)])
+    ctx = medgp_amd.Context(7, Q, D, R)
+    ctx.reserve(P, max(ns), P)
+    ctx.set_patients(np.arange(P), pts)
+    ctx.set_prior(-1, *synth.hier_gamma_prior(Q, D, R, 0.01))
+    pr = O.Prior.hier_gamma(Q, D, R, 0.01, 0.01)
+    nlml, grad, st = ctx.nlml_grad(np.arange(P), th, True)
+    nlml0, _, st0 = ctx.nlml_grad(np.arange(P), th, False)
+    for p in range(P):
+        ref = O.nlml_grad(7, Q, D, R, *pts[p], th[p], prior=pr, nthreads=4)
+        assert st[p] == ref["status"] == st0[p] == 0
+        assert_parity(nlml[p], grad[p], ref, f"D{D}_p{p}")
+        assert abs(nlml0[p] - ref["nlml"]) <= 1e-10 * abs(ref["nlml"])
+    m2 = np.array([0, D - 1, D // 2], np.int32)
+    t2 = np.array([5.0, 50.0, 150.0], np.float32)
+    mean, var, pst = ctx.fit_predict(0, th[0], m2, t2)
+    rp = O.fit_predict(7, Q, D, R, *pts[0], th[0], m2, t2)
+    assert pst == 0
+    np.testing.assert_allclose(mean, rp["mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(var, rp["var"], rtol=1e-5, atol=1e-6)
+    ctx.close()
