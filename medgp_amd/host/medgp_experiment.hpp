@@ -21,6 +21,7 @@ public:
     bool load(const std::string &cfg_name);
     const std::string &error() const { return err; }
 
+    std::string get_data_dir() const { return exp_data_dir; }
     std::string get_exp_train_dir() const { return exp_train_dir; }
     std::string get_exp_test_dir() const { return exp_test_dir; }
     std::string get_exp_kernel_dir() const { return exp_kernel_dir; }

@@ -1,12 +1,19 @@
 // medgp_train.cpp -- MI355X host of MedGP's per-patient training (the reference's main_one_train,
 // ref: main_one_train.cpp:41-324), with the same CLI, config, inputs and output files:
 //     medgp_train --cfg exp_setup.json --pan <PAN> --thread <n>
-// plus a cohort mode that is the point of the GPU build: several patients are trained in LOCK STEP on one
+// plus a cohort mode that is the point of the GPU build: patients are trained in LOCK STEP on one
 // device -- the random-init screening (HOT LOOP A, ref :228-253) and every optimiser step (HOT LOOP B,
-// ref c_optimizer_scg.cpp:65,120,221) of all patients become single batched medgp_nlml_grad calls:
-//     medgp_train --cfg exp_setup.json --pan-list pans.txt [--device d] [--max-batch B]
-// Outputs per patient (ref :257-323): train_init_hyp_<PAN>.bin, train_hyp_<PAN>.bin, train_var_hyp_<PAN>.bin
-// (prior mode 2), train_num_<PAN>.txt, train_flag_<PAN>.txt.
+// ref c_optimizer_scg.cpp:65,120,221) of all resident patients become single batched medgp_nlml_grad calls:
+//     medgp_train --cfg exp_setup.json --pan-list pans.txt [--device d] [--resident R] [--max-batch B] [--queue file]
+// Round 5: CONTINUOUS ADMISSION.  The trainer is long lived: it keeps up to --resident patients on the device and, whenever
+// patients finish (early stop of the variational-EM loop, ref: util/c_optimizer_varEM.cpp:89-95; failed line searches, ref:
+// util/c_optimizer_scg.cpp:125-131; budgets), pulls the next patients of the list into the freed slots -- load (a background
+// thread reads ahead), upload, screening, optimiser start -- so the lock-step batches stay full until the list is exhausted.
+// The list is walked longest patient first (cost model N^3); with --queue <file> several trainers (one per GPU, see
+// medgp_amd/train_cohort.py) take their patients from ONE shared counter (flock), which balances them the way the reference's
+// scheduler does with one job per patient (ref: medgpc/util/run_exp_generator.py:213-260).
+// Outputs per patient (ref :257-323), written when the patient finishes: train_init_hyp_<PAN>.bin, train_hyp_<PAN>.bin,
+// train_var_hyp_<PAN>.bin (prior mode 2), train_num_<PAN>.txt, train_flag_<PAN>.txt.
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -24,8 +31,13 @@
 #include <iostream>
 #include <limits>
 #include <memory>
+#include <numeric>
 #include <string>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 
 #include "medgp_experiment.hpp"
 #include "medgp_host.hpp"
@@ -42,9 +54,11 @@ namespace {
 
 struct Patient {
     string PAN;
+    int index = -1;            // position in the patient list (output order of the closing summary)
     vector<int> meta;
     vector<float> t, y;
     bool sample_flag = true, success = false, flag_data = false;
+    string load_log, load_err;
     int slot = -1;
     c_prior prior;
     double best_loss = std::numeric_limits<double>::max();
@@ -77,11 +91,132 @@ bool upload_priors(medgp_ctx *ctx, const vector<Patient *> &ps, int H, WorkPool 
     return medgp_set_priors(ctx, (int)n, slots.data(), flag.data(), type.data(), ex.data(), p0.data(), p1.data()) == 0;
 }
 
+// the shared work counter: atomic fetch-and-increment of the integer in `path` (the same file protocol as
+// medgp_amd/train_cohort.py take_ticket); without a path, a counter of this process
+struct Tickets {
+    string path;
+    std::atomic<long long> local{0};
+    long long take() {
+        if (path.empty()) return local.fetch_add(1);
+        const int fd = open(path.c_str(), O_RDWR | O_CREAT, 0644);
+        if (fd < 0) return -1;
+        long long k = -1;
+        if (flock(fd, LOCK_EX) == 0) {
+            char buf[40] = {0};
+            const ssize_t r = read(fd, buf, sizeof buf - 1);
+            k = (r > 0) ? atoll(buf) : 0;
+            const string s = std::to_string(k + 1);
+            if (lseek(fd, 0, SEEK_SET) != 0 || ftruncate(fd, 0) != 0 || write(fd, s.data(), s.size()) != (ssize_t)s.size()) k = -1;
+            flock(fd, LOCK_UN);
+        }
+        close(fd);
+        return k;
+    }
+};
+
+// observations of a patient from the headers of its feature files (first token = count, ref: dataio/c_experiment.cpp:296-299);
+// 0 when a file is missing (the real load then reports it)
+int header_count(const c_experiment &ex, const string &PAN) {
+    int n = 0;
+    for (int fi : ex.get_feature_index()) {
+        std::ifstream f((ex.get_data_dir() + PAN + "/feature" + std::to_string((long long)fi) + ".txt").c_str());
+        float c = 0;
+        if (f >> c) n += (int)c;
+    }
+    return n;
+}
+
+// Background reader: takes tickets, loads the patients they name (ref: dataio/c_experiment.cpp:254-309, D feature files each) and
+// keeps up to `cap` of them ready, so that an admission never waits for the file system while the device idles.  (Not more than an
+// eighth of the resident set: with a shared counter, patients held ready here are patients an idle trainer elsewhere cannot take.)
+class Loader {
+public:
+    Loader(const c_experiment &ex_, const vector<string> &pans_, const vector<int> &order_, Tickets &tk_, size_t cap_, int nthreads)
+        : ex(ex_), pans(pans_), order(order_), tk(tk_), cap(std::max<size_t>(cap_, 1)) {
+        for (int i = 0; i < std::max(1, nthreads); i++) th.emplace_back([this] { run(); });
+        live = (int)th.size();
+    }
+    ~Loader() {
+        { std::lock_guard<std::mutex> l(mu); stop = true; }
+        cv_space.notify_all();
+        for (auto &t : th) t.join();
+    }
+    // up to `want` loaded patients; blocks only when `block` and nothing is ready while readers are still at work
+    vector<std::unique_ptr<Patient>> take(size_t want, bool block) {
+        vector<std::unique_ptr<Patient>> out;
+        std::unique_lock<std::mutex> l(mu);
+        // (blocking: a full wave -- the caller's device is idle, one large admission beats many small ones)
+        if (block) cv_ready.wait(l, [&] { return ready.size() >= std::min(want, cap) || live == 0; });
+        while (!ready.empty() && out.size() < want) { out.push_back(std::move(ready.front())); ready.pop_front(); }
+        l.unlock();
+        cv_space.notify_all();
+        return out;
+    }
+    bool exhausted() {   // nothing ready and nothing will come
+        std::lock_guard<std::mutex> l(mu);
+        return ready.empty() && live == 0;
+    }
+    long long taken() const { return n_taken.load(); }
+
+private:
+    void run() {
+        while (true) {
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv_space.wait(l, [&] { return stop || ready.size() + inflight < cap; });
+                if (stop) break;
+                inflight++;
+            }
+            const long long k = tk.take();
+            std::unique_ptr<Patient> p;
+            if (k >= 0 && k < (long long)order.size()) {
+                n_taken.fetch_add(1);
+                p.reset(new Patient());
+                p->index = order[(size_t)k];
+                p->PAN = pans[(size_t)p->index];
+                c_experiment e = ex;                 // own error string per reader
+                std::ostringstream os;
+                os << "running individual training..." << endl << "current patinet PAN = " << p->PAN << endl;
+                if (!e.get_one_patient_data(p->PAN, p->meta, p->t, p->y)) p->load_err = e.error();
+                else {
+                    os << "current number of data points = " << p->t.size() << endl;
+                    vector<int> count_array(e.get_feature_index().size(), 0);
+                    for (size_t i = 0; i < p->t.size(); i++) count_array[p->meta[i]] += 1;
+                    for (int c : count_array) if (c < 2) { p->sample_flag = false; break; }   // ref :185-197
+                    if (!p->sample_flag) os << "skip due to insufficient # of samples" << endl;
+                }
+                p->load_log = os.str();
+            }
+            std::unique_lock<std::mutex> l(mu);
+            inflight--;
+            if (p) ready.push_back(std::move(p));
+            else { live--; l.unlock(); cv_ready.notify_all(); return; }   // the list is exhausted (or the counter file failed)
+            l.unlock();
+            cv_ready.notify_all();
+        }
+        std::lock_guard<std::mutex> l(mu);
+        live--;
+        cv_ready.notify_all();
+    }
+    const c_experiment &ex;
+    const vector<string> &pans;
+    const vector<int> &order;
+    Tickets &tk;
+    size_t cap, inflight = 0;
+    int live = 0;
+    bool stop = false;
+    std::atomic<long long> n_taken{0};
+    std::deque<std::unique_ptr<Patient>> ready;
+    std::mutex mu;
+    std::condition_variable cv_ready, cv_space;
+    vector<std::thread> th;
+};
+
 }  // namespace
 
 static int train_main(int argc, const char *argv[]) {
-    string exp_cfg, pan_arg, pan_list;
-    int thread_num = 1, device = 0, max_batch = 1024, host_threads = 0, pingpong_min = 1024;
+    string exp_cfg, pan_arg, pan_list, queue_file, order_arg = "size";
+    int thread_num = 1, device = 0, max_batch = 1024, host_threads = 0, pingpong_min = 1024, resident = 1024, admit_min = -1, max_n_arg = 0;
     bool pin_route = false;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--cfg") && i + 1 < argc) exp_cfg = argv[++i];
@@ -91,15 +226,22 @@ static int train_main(int argc, const char *argv[]) {
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--max-batch") && i + 1 < argc) max_batch = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--host-threads") && i + 1 < argc) host_threads = atoi(argv[++i]);   // 0 = usable cores (<= 8)
-        else if (!strcmp(argv[i], "--pingpong-min") && i + 1 < argc) pingpong_min = atoi(argv[++i]);   // active patients from which the lock-step loop splits them in two alternating halves
+        else if (!strcmp(argv[i], "--pingpong-min") && i + 1 < argc) pingpong_min = atoi(argv[++i]);   // resident patients from which the lock-step loop runs them as two alternating halves
+        else if (!strcmp(argv[i], "--resident") && i + 1 < argc) resident = atoi(argv[++i]);           // patients kept on the device at once (continuous admission)
+        else if (!strcmp(argv[i], "--admit-min") && i + 1 < argc) admit_min = atoi(argv[++i]);         // free places of a group from which new patients are admitted (default: an eighth of the group)
+        else if (!strcmp(argv[i], "--queue") && i + 1 < argc) queue_file = argv[++i];                  // shared work counter: several trainers walk ONE list
+        else if (!strcmp(argv[i], "--order") && i + 1 < argc) order_arg = argv[++i];                   // size (longest first, default) | list
+        else if (!strcmp(argv[i], "--max-n") && i + 1 < argc) max_n_arg = atoi(argv[++i]);             // largest observation count of the list (skips the header scan)
         else if (!strcmp(argv[i], "--pin-route")) pin_route = true;   // medgp_pin_route: bit-identical results whatever the batch (slower for few large patients)
         else { cout << "Error: unknown argument: " << argv[i] << endl; return 1; }
     }
     if (exp_cfg.empty() || (pan_arg.empty() && pan_list.empty())) {
         cout << "usage:\n\t --cfg:\t the JSON configuration file\n\t --pan:\t ID of the training patient (comma separated for several)\n"
-             << "\t --pan-list:\t file with one patient ID per line (cohort mode)\n\t --thread:\t accepted for compatibility, unused\n";
+             << "\t --pan-list:\t file with one patient ID per line, optionally followed by its observation count (cohort mode)\n"
+             << "\t --resident:\t patients resident on the device at once\n\t --queue:\t shared work-counter file\n\t --thread:\t accepted for compatibility, unused\n";
         return 1;
     }
+    if (order_arg != "size" && order_arg != "list") { cout << "Error: --order must be size or list" << endl; return 1; }
     cout << "current configuration file: " << exp_cfg << endl;
     cout << "current threading number for matrix operation: " << thread_num << " (ignored: the GPU path has no host threads)" << endl;
 
@@ -110,192 +252,234 @@ static int train_main(int argc, const char *argv[]) {
     const int H = curr_exp.get_hyp_num();
 
     vector<string> pans;
+    vector<int> nhint;      // observation count per patient: second column of the list, or -1
     {
         size_t a = 0;
-        while (a < pan_arg.size()) { size_t b = pan_arg.find(',', a); if (b == string::npos) b = pan_arg.size(); if (b > a) pans.push_back(pan_arg.substr(a, b - a)); a = b + 1; }
+        while (a < pan_arg.size()) { size_t b = pan_arg.find(',', a); if (b == string::npos) b = pan_arg.size(); if (b > a) { pans.push_back(pan_arg.substr(a, b - a)); nhint.push_back(-1); } a = b + 1; }
         if (!pan_list.empty()) {
             std::ifstream f(pan_list.c_str());
             if (!f) { cout << "ERROR: File " << pan_list << " could not be opened." << endl; return 1; }
-            string s;
-            while (f >> s) pans.push_back(s);
+            string line;
+            while (std::getline(f, line)) {
+                std::istringstream ls(line);
+                string s;
+                long long n = -1;
+                if (!(ls >> s)) continue;
+                if (!(ls >> n)) n = -1;
+                pans.push_back(s);
+                nhint.push_back((int)n);
+            }
         }
     }
     time_t t_start;
     time(&t_start);
-
-    // ---------------- load patients, data-quality check (ref :185-197).  The reference loads ONE patient per process
-    // (ref: dataio/c_experiment.cpp:254-309, D feature files each); a cohort is loaded by a pool of host threads over the
-    // patients, the log lines are printed afterwards in patient order, and the whole cohort goes to the device as ONE packed
-    // upload (medgp_set_patients: one transfer, one scatter kernel)
     if (host_threads <= 0) host_threads = std::min(8, usable_cores());
     WorkPool pool(std::max(1, host_threads));
-    const auto t_load0 = std::chrono::steady_clock::now();
-    vector<std::unique_ptr<Patient>> pts(pans.size());
-    vector<string> load_log(pans.size()), load_err(pans.size());
-    pool.parallel_for((int)pans.size(), [&](int i) {
-        c_experiment ex = curr_exp;                 // own error string per task
-        std::unique_ptr<Patient> p(new Patient());
-        p->PAN = pans[i];
-        std::ostringstream os;
-        os << "running individual training..." << endl << "current patinet PAN = " << p->PAN << endl;
-        if (!ex.get_one_patient_data(p->PAN, p->meta, p->t, p->y)) { load_err[i] = ex.error(); pts[i] = std::move(p); return; }
-        os << "current number of data points = " << p->t.size() << endl;
-        vector<int> count_array(ex.get_feature_index().size(), 0);
-        for (size_t k = 0; k < p->t.size(); k++) count_array[p->meta[k]] += 1;
-        for (int c : count_array) if (c < 2) { p->sample_flag = false; break; }
-        if (!p->sample_flag) os << "skip due to insufficient # of samples" << endl;
-        load_log[i] = os.str();
-        pts[i] = std::move(p);
-    });
-    int max_n = 1;
-    for (size_t i = 0; i < pans.size(); i++) {
-        cout << load_log[i];
-        if (!load_err[i].empty()) { cout << "ERROR: " << load_err[i] << endl; return 1; }
-        max_n = std::max(max_n, (int)pts[i]->t.size());
-    }
-    const auto t_load1 = std::chrono::steady_clock::now();
-
-    // ---------------- device context: every usable patient resident in its own slot
-    vector<Patient *> live;
-    for (auto &p : pts) if (p->sample_flag) live.push_back(p.get());
-    medgp_ctx *ctx = nullptr;
-    const int nslot = std::max<int>(1, (int)live.size());
-    if (!live.empty()) {
-        if (medgp_create(&ctx, device, kidx, kparam[0], kparam[1], kparam[2])) { cout << "ERROR: " << medgp_last_error(nullptr) << endl; return 1; }
-        {   // evaluations that can exist at once, and what fits a memory budget: every batch entry owns two ldn x ldn fp64
-            // matrices (medgp_reserve allocates them up front); the screening and lock-step loops chunk by max_batch
-            const long long ldn = (max_n + 63) / 64 * 64;
-            const long long want = (long long)live.size() * std::max(curr_exp.get_scg_init_num(), 1);
-            const long long fit = std::max<long long>(1, (48LL << 30) / (16 * ldn * ldn + 4096));
-            max_batch = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(std::max(1, max_batch), want), fit));
-        }
-        if (medgp_reserve(ctx, nslot, max_n, max_batch)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
-        if (pin_route && medgp_pin_route(ctx, 1)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
-        // packed SoA cohort arrays (stacked meta / t / y with offsets)
-        vector<int32_t> slots(live.size());
-        vector<int64_t> offs(live.size() + 1, 0);
-        for (size_t s = 0; s < live.size(); s++) { live[s]->slot = (int)s; slots[s] = (int)s; offs[s + 1] = offs[s] + (int64_t)live[s]->t.size(); }
-        vector<int32_t> meta_all((size_t)offs.back());
-        vector<float> t_all((size_t)offs.back()), y_all((size_t)offs.back());
-        pool.parallel_for((int)live.size(), [&](int s) {
-            const Patient &p = *live[s];
-            std::copy(p.meta.begin(), p.meta.end(), meta_all.begin() + offs[s]);
-            std::copy(p.t.begin(), p.t.end(), t_all.begin() + offs[s]);
-            std::copy(p.y.begin(), p.y.end(), y_all.begin() + offs[s]);
-        });
-        if (medgp_set_patients(ctx, (int)live.size(), slots.data(), offs.data(), kidx == 7 ? meta_all.data() : nullptr, t_all.data(), y_all.data())) {
-            cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1;
-        }
-        for (Patient *p : live) p->prior.initialize_param(curr_exp.get_cov_num(), curr_exp.get_mean_num(), curr_exp.get_lik_num());   // ref :222-226
-        cout << "finish initialization of prior" << endl;
-    }
-    {
-        const auto t_up = std::chrono::steady_clock::now();
-        cout << "INFO: loaded " << pans.size() << " patients x " << curr_exp.get_feature_index().size() << " feature files in "
-             << std::chrono::duration<double>(t_load1 - t_load0).count() << " s on " << pool.size() << " host threads; packed upload "
-             << std::chrono::duration<double>(t_up - t_load1).count() << " s" << endl;
-    }
-
-    // ---------------- HOT LOOP A: random-init screening, nlml only (ref :228-253), batched over (patient, init)
-    vector<vector<double>> global_hyp_array;
-    curr_exp.get_global_hyp(global_hyp_array);
-    const int ninit = curr_exp.get_scg_init_num();
-    if (!live.empty()) {
-        vector<vector<double>> loss(live.size(), vector<double>(ninit, 0.0));
-        vector<vector<int32_t>> stat(live.size(), vector<int32_t>(ninit, 0));
-        vector<int32_t> slots;
-        vector<double> thetas, nl;
-        vector<int32_t> st;
-        vector<std::pair<int, int>> who;
-        auto flush = [&]() -> bool {
-            if (slots.empty()) return true;
-            nl.resize(slots.size()); st.resize(slots.size());
-            if (medgp_nlml_grad(ctx, (int)slots.size(), slots.data(), thetas.data(), 0, nl.data(), nullptr, st.data())) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
-            for (size_t k = 0; k < slots.size(); k++) { loss[who[k].first][who[k].second] = nl[k]; stat[who[k].first][who[k].second] = st[k]; }
-            slots.clear(); thetas.clear(); who.clear();
-            return true;
-        };
-        for (size_t s = 0; s < live.size(); s++)
-            for (int init = 0; init < ninit; init++) {
-                slots.push_back(live[s]->slot);
-                thetas.insert(thetas.end(), global_hyp_array[init].begin(), global_hyp_array[init].end());
-                who.push_back({(int)s, init});
-                if ((int)slots.size() == max_batch && !flush()) return 1;
-            }
-        if (!flush()) return 1;
-        for (size_t s = 0; s < live.size(); s++) {
-            Patient &p = *live[s];
-            p.success = false;
-            for (int init = 0; init < ninit; init++) {
-                const bool ok = stat[s][init] >= 0;
-                p.success = ok;
-                if (!ok) { cout << "WARNING: failed in computing objective!" << endl; break; }   // ref :243-246
-                if (loss[s][init] < p.best_loss) { p.best_loss = loss[s][init]; p.best_init = global_hyp_array[init]; }
-            }
-            cout << "INFO: finish initialization " << ninit << " for " << p.PAN << "; best loss = " << p.best_loss << endl;
-            c_experiment::output_double_bin(curr_exp.get_exp_train_dir() + "train_init_hyp_" + p.PAN, p.best_init);
-        }
-    }
-
-    // ---------------- HOT LOOP B: optimisation in lock step (ref :260-292)
-    vector<Patient *> running;
-    const bool verbose = live.size() == 1;   // the per-iteration lines of one patient; a cohort's state machines run on host threads
-    for (Patient *p : live) {
-        if (!p->success) continue;
-        p->prior.setup_param(kidx, kparam, curr_exp.get_prior_mode(), curr_exp.get_prior_hyp());
-        p->use_vem = curr_exp.get_prior_mode() == 2;
-        if (p->use_vem) p->vem.start((-1) * curr_exp.get_scg_max_iter_num(), p->best_init, &p->prior, kparam, curr_exp.get_lik_num(), curr_exp.get_prior_sub_opt_iter(), verbose);
-        else p->scg.start((-1) * curr_exp.get_scg_max_iter_num(), p->best_init);
-        p->active = p->use_vem ? !p->vem.done() : !p->scg.done();
-        running.push_back(p);
-    }
-    if (ctx && !upload_priors(ctx, running, H, pool)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
-    cout << "start doing optimization" << endl;
-    long long total_evals = 0, steps = 0;
-    double t_wait = 0.0, t_host = 0.0;   // seconds blocked in medgp_wait / in the optimiser state machines (incl. request copies, prior uploads)
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    const auto t_loop0 = now();
+
+    // ---------------- sizes (for the walk order and the device capacity): the list's second column, else the feature files' headers
+    const auto t_scan0 = now();
+    {
+        vector<int> need;
+        for (size_t i = 0; i < pans.size(); i++) if (nhint[i] < 0) need.push_back((int)i);
+        pool.parallel_for((int)need.size(), [&](int k) { nhint[need[k]] = header_count(curr_exp, pans[need[k]]); });
+    }
+    int max_n = std::max(1, max_n_arg);
+    for (int n : nhint) max_n = std::max(max_n, n);
+    vector<int> order(pans.size());
+    std::iota(order.begin(), order.end(), 0);
+    if (order_arg == "size") std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nhint[a] > nhint[b]; });
+    const double t_scan = secs(t_scan0, now());
+
+    // ---------------- device context: `resident` patient slots; per-entry matrices are allocated by the library as the calls need them
+    resident = std::max(1, std::min<int>(resident, (int)pans.size()));
+    const int ninit = curr_exp.get_scg_init_num();
+    max_batch = std::max(1, max_batch);
+    medgp_ctx *ctx = nullptr;
+    if (medgp_create(&ctx, device, kidx, kparam[0], kparam[1], kparam[2])) { cout << "ERROR: " << medgp_last_error(nullptr) << endl; return 1; }
+    if (medgp_reserve(ctx, resident, max_n, std::max(max_batch, resident))) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
+    if (pin_route && medgp_pin_route(ctx, 1)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
+    vector<int> free_slots;
+    for (int s = resident - 1; s >= 0; s--) free_slots.push_back(s);
+
+    Tickets tickets;
+    tickets.path = queue_file;
+    Loader loader(curr_exp, pans, order, tickets, (size_t)std::max(2, resident / 8), std::max(1, std::min(4, host_threads / 2)));
+
+    vector<vector<double>> global_hyp_array;
+    curr_exp.get_global_hyp(global_hyp_array);
+    const bool verbose = pans.size() == 1;   // the per-iteration lines of one patient; a cohort's state machines run on host threads
+
+    // closing summary lines in list order (the reference prints one per process)
+    vector<string> final_line(pans.size());
+    vector<uint8_t> mine(pans.size(), 0);
+    long long n_finished = 0;
+    auto finish = [&](Patient &p) {   // outputs of one patient (ref :297-323); its device slot goes back to the pool
+        if (p.sample_flag && p.success) {
+            if (p.use_vem) { p.best_loss = p.vem.opt_loss; p.opt_parameter = p.vem.opt_parameter; }
+            else { p.best_loss = p.scg.opt_loss; p.opt_parameter = p.scg.opt_parameter; }
+            c_experiment::output_double_bin(curr_exp.get_exp_train_dir() + "train_hyp_" + p.PAN, p.opt_parameter);
+            if (curr_exp.get_prior_mode() == 2)
+                c_experiment::output_double_bin(curr_exp.get_exp_train_dir() + "train_var_hyp_" + p.PAN, p.prior.get_cov_varEM_all());
+        }
+        p.flag_data = p.sample_flag && p.success;
+        std::ostringstream os;
+        os << "finish individual id: " << p.PAN << " w/ " << p.t.size() << " samples; flag = " << p.flag_data
+           << "; final loss = " << p.best_loss << endl;
+        final_line[(size_t)p.index] = os.str();
+        mine[(size_t)p.index] = 1;
+        c_experiment::output_int_txt(curr_exp.get_exp_train_dir() + "train_num_" + p.PAN, {(int)p.t.size()});
+        c_experiment::output_int_txt(curr_exp.get_exp_train_dir() + "train_flag_" + p.PAN, {(int)p.flag_data});
+        if (p.slot >= 0) { free_slots.push_back(p.slot); p.slot = -1; }
+        n_finished++;
+    };
+
+    long long total_evals = 0, steps = 0, screen_evals = 0, admissions = 0;
+    double t_wait = 0.0, t_host = 0.0, t_screen = 0.0, t_admit = 0.0;   // seconds blocked in medgp_wait / in the optimiser state machines / in the screening calls / in admissions as a whole
+    vector<std::unique_ptr<Patient>> owned;   // every patient currently resident (or being admitted)
+
+    // ---------------- admission: upload, HOT LOOP A (random-init screening, nlml only, ref :228-253, batched over (patient, init)),
+    // optimiser start (ref :260-292).  Returns the patients that now take part in the lock-step loop.
+    auto admit = [&](vector<std::unique_ptr<Patient>> &&in, vector<Patient *> &started) -> bool {
+        const auto ta0 = now();
+        vector<Patient *> live;
+        for (auto &up : in) {
+            Patient *p = up.get();
+            cout << p->load_log;
+            if (!p->load_err.empty()) { cout << "ERROR: " << p->load_err << endl; return false; }
+            if ((int)p->t.size() > max_n) { cout << "ERROR: patient " << p->PAN << " has " << p->t.size() << " observations, more than the " << max_n << " the list announced" << endl; return false; }
+            owned.push_back(std::move(up));
+            if (!p->sample_flag) { finish(*p); continue; }
+            p->slot = free_slots.back(); free_slots.pop_back();
+            live.push_back(p);
+        }
+        in.clear();
+        if (live.empty()) { t_admit += secs(ta0, now()); return true; }
+        admissions++;
+        {   // packed SoA arrays (stacked meta / t / y with offsets): one transfer, one scatter kernel
+            vector<int32_t> slots(live.size());
+            vector<int64_t> offs(live.size() + 1, 0);
+            for (size_t s = 0; s < live.size(); s++) { slots[s] = live[s]->slot; offs[s + 1] = offs[s] + (int64_t)live[s]->t.size(); }
+            vector<int32_t> meta_all((size_t)offs.back());
+            vector<float> t_all((size_t)offs.back()), y_all((size_t)offs.back());
+            pool.parallel_for((int)live.size(), [&](int s) {
+                const Patient &p = *live[s];
+                std::copy(p.meta.begin(), p.meta.end(), meta_all.begin() + offs[s]);
+                std::copy(p.t.begin(), p.t.end(), t_all.begin() + offs[s]);
+                std::copy(p.y.begin(), p.y.end(), y_all.begin() + offs[s]);
+            });
+            if (medgp_set_patients(ctx, (int)live.size(), slots.data(), offs.data(), kidx == 7 ? meta_all.data() : nullptr, t_all.data(), y_all.data())) {
+                cout << "ERROR: " << medgp_last_error(ctx) << endl; return false;
+            }
+        }
+        vector<Patient *> unprior;   // (a slot may still carry its previous patient's prior: the screening runs without one, ref :222-226)
+        for (Patient *p : live) { p->prior.initialize_param(curr_exp.get_cov_num(), curr_exp.get_mean_num(), curr_exp.get_lik_num()); unprior.push_back(p); }
+        if (!upload_priors(ctx, unprior, H, pool)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
+        if (admissions == 1) cout << "finish initialization of prior" << endl;
+        {
+            const auto ts0 = now();
+            vector<vector<double>> loss(live.size(), vector<double>(ninit, 0.0));
+            vector<vector<int32_t>> stat(live.size(), vector<int32_t>(ninit, 0));
+            vector<int32_t> slots;
+            vector<double> thetas, nl;
+            vector<int32_t> st;
+            vector<std::pair<int, int>> who;
+            long long bytes = 0;   // device matrices the queued entries need (two padded n x n fp64 matrices each): a call stays below 48 GB
+            auto flush = [&]() -> bool {
+                if (slots.empty()) return true;
+                nl.resize(slots.size()); st.resize(slots.size());
+                if (medgp_nlml_grad(ctx, (int)slots.size(), slots.data(), thetas.data(), 0, nl.data(), nullptr, st.data())) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
+                for (size_t k = 0; k < slots.size(); k++) { loss[who[k].first][who[k].second] = nl[k]; stat[who[k].first][who[k].second] = st[k]; }
+                screen_evals += (long long)slots.size();
+                slots.clear(); thetas.clear(); who.clear(); bytes = 0;
+                return true;
+            };
+            for (size_t s = 0; s < live.size(); s++) {
+                const long long ldp = ((long long)live[s]->t.size() + 63) / 64 * 64, per = 16 * ldp * ldp;
+                for (int init = 0; init < ninit; init++) {
+                    if (!slots.empty() && bytes + per > (48LL << 30) && !flush()) return false;
+                    slots.push_back(live[s]->slot);
+                    thetas.insert(thetas.end(), global_hyp_array[init].begin(), global_hyp_array[init].end());
+                    who.push_back({(int)s, init});
+                    bytes += per;
+                    if ((int)slots.size() == max_batch && !flush()) return false;
+                }
+            }
+            if (!flush()) return false;
+            for (size_t s = 0; s < live.size(); s++) {
+                Patient &p = *live[s];
+                p.success = false;
+                for (int init = 0; init < ninit; init++) {
+                    const bool ok = stat[s][init] >= 0;
+                    p.success = ok;
+                    if (!ok) { cout << "WARNING: failed in computing objective!" << endl; break; }   // ref :243-246
+                    if (loss[s][init] < p.best_loss) { p.best_loss = loss[s][init]; p.best_init = global_hyp_array[init]; }
+                }
+                cout << "INFO: finish initialization " << ninit << " for " << p.PAN << "; best loss = " << p.best_loss << endl;
+                c_experiment::output_double_bin(curr_exp.get_exp_train_dir() + "train_init_hyp_" + p.PAN, p.best_init);
+            }
+            t_screen += secs(ts0, now());
+        }
+        vector<Patient *> go;
+        for (Patient *p : live) {
+            if (!p->success) { finish(*p); continue; }
+            p->prior.setup_param(kidx, kparam, curr_exp.get_prior_mode(), curr_exp.get_prior_hyp());
+            p->use_vem = curr_exp.get_prior_mode() == 2;
+            if (p->use_vem) p->vem.start((-1) * curr_exp.get_scg_max_iter_num(), p->best_init, &p->prior, kparam, curr_exp.get_lik_num(), curr_exp.get_prior_sub_opt_iter(), verbose);
+            else p->scg.start((-1) * curr_exp.get_scg_max_iter_num(), p->best_init);
+            p->active = p->use_vem ? !p->vem.done() : !p->scg.done();
+            go.push_back(p);
+        }
+        if (!upload_priors(ctx, go, H, pool)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
+        for (Patient *p : go) { if (p->active) started.push_back(p); else finish(*p); }
+        t_admit += secs(ta0, now());
+        return true;
+    };
+
+    // ---------------- HOT LOOP B: optimisation in lock step (ref :260-292)
     // Groups of patients that advance together: each group's step is one batched evaluation on one of the two asynchronous lanes
     // of the context (medgp_nlml_grad_async); while the device works on one group the host threads run the state machines of the
-    // other (ref: the strictly sequential objective calls of util/c_optimizer_scg.cpp:65,120,221).  One group (no overlap, the
-    // whole active set in one launch -- the most efficient use of the device) unless the active set is large enough that each
-    // half still fills the chip (--pingpong-min) or exceeds max_batch.
-    struct Group { vector<Patient *> mem; double *th = nullptr, *nl = nullptr, *gr = nullptr; int32_t *st = nullptr; vector<int32_t> slots; int nb = 0; };
-    vector<Group> groups;
-    {
-        vector<Patient *> act;
-        for (Patient *p : running) if (p->active) act.push_back(p);
-        int G = (int)((act.size() + max_batch - 1) / std::max(1, max_batch));
-        if ((int)act.size() >= 2 * std::max(1, pingpong_min)) G = std::max(G, 2);
-        G = std::max(G, 1);
-        const size_t per = (act.size() + G - 1) / std::max(G, 1);
-        for (int g = 0; g < G; g++) {
-            Group gp;
-            for (size_t k = g * per; k < std::min(act.size(), (g + 1) * per); k++) gp.mem.push_back(act[k]);
-            if (gp.mem.empty()) continue;
-            const size_t cap = gp.mem.size();
-            gp.th = (double *)medgp_host_alloc(sizeof(double) * cap * H);
-            gp.nl = (double *)medgp_host_alloc(sizeof(double) * cap);
-            gp.gr = (double *)medgp_host_alloc(sizeof(double) * cap * H);
-            gp.st = (int32_t *)medgp_host_alloc(sizeof(int32_t) * cap);
-            if (!gp.th || !gp.nl || !gp.gr || !gp.st) { cout << "ERROR: pinned host allocation failed" << endl; return 1; }
-            groups.push_back(std::move(gp));
-        }
+    // other (ref: the strictly sequential objective calls of util/c_optimizer_scg.cpp:65,120,221).  One group (no overlap, all
+    // resident patients in one launch) unless there are enough of them that each half still fills the chip (--pingpong-min) or
+    // they exceed max_batch.  A group that has lost an eighth of its members (--admit-min) takes new patients in before its next step.
+    struct Group { vector<Patient *> mem; double *th = nullptr, *nl = nullptr, *gr = nullptr; int32_t *st = nullptr; vector<int32_t> slots; int nb = 0; size_t cap = 0; };
+    int G = (resident + max_batch - 1) / max_batch;
+    if (resident >= 2 * std::max(1, pingpong_min)) G = std::max(G, 2);
+    G = std::max(G, 1);
+    const size_t gcap = ((size_t)resident + G - 1) / G;            // members a group is filled up to
+    const size_t bufcap = std::min<size_t>((size_t)resident, std::max<size_t>((size_t)max_batch, gcap));   // (a merged group may hold everybody that is left)
+    vector<Group> groups((size_t)G);
+    for (Group &g : groups) {
+        g.cap = gcap;
+        g.th = (double *)medgp_host_alloc(sizeof(double) * bufcap * H);
+        g.nl = (double *)medgp_host_alloc(sizeof(double) * bufcap);
+        g.gr = (double *)medgp_host_alloc(sizeof(double) * bufcap * H);
+        g.st = (int32_t *)medgp_host_alloc(sizeof(int32_t) * bufcap);
+        if (!g.th || !g.nl || !g.gr || !g.st) { cout << "ERROR: pinned host allocation failed" << endl; return 1; }
     }
-    // rows of g.th hold the pending requests of g.mem (same order); feed() refreshes them in the same parallel pass that runs the
-    // state machines, so a lock-step step costs ONE fork/join of the host threads
-    auto fill_requests = [&](Group &g) {
-        g.nb = (int)g.mem.size();
-        pool.parallel_for(g.nb, [&](int k) {
-            Patient *p = g.mem[k];
-            const vector<double> &rq = p->use_vem ? p->vem.request() : p->scg.request();
-            std::copy(rq.begin(), rq.end(), g.th + (size_t)k * H);
-        });
-    };
-    for (Group &g : groups) fill_requests(g);
+    if (admit_min < 0) admit_min = std::max<int>(1, (int)gcap / 8);
     const size_t groups_initial = groups.size();
     int merges = 0;
+    bool announced = false;
+    // new members: their first requests go into the rows behind the group's current members
+    auto refill = [&](Group &g, bool must) -> bool {
+        if (loader.exhausted()) return true;
+        const size_t room = g.cap > g.mem.size() ? g.cap - g.mem.size() : 0;
+        if (room == 0 || (!must && room < (size_t)admit_min && !g.mem.empty())) return true;
+        // do not wait for the reader while there is work on the device; with an empty group (start, or everybody finished at once) wait
+        vector<std::unique_ptr<Patient>> in = loader.take(std::min(room, free_slots.size()), must || g.mem.empty());
+        if (in.empty()) return true;
+        vector<Patient *> started;
+        if (!admit(std::move(in), started)) return false;
+        if (!announced && !started.empty()) { cout << "start doing optimization" << endl; announced = true; }
+        for (Patient *p : started) {
+            const vector<double> &rq = p->use_vem ? p->vem.request() : p->scg.request();
+            std::copy(rq.begin(), rq.end(), g.th + g.mem.size() * H);
+            g.mem.push_back(p);
+        }
+        return true;
+    };
     auto submit = [&](Group &g, int lane) -> bool {   // queue the evaluation of the group's pending requests
         g.nb = (int)g.mem.size();
         if (g.nb == 0) return true;
@@ -329,62 +513,75 @@ static int train_main(int argc, const char *argv[]) {
         if (!upload_priors(ctx, ch, H, pool)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
         int w = 0;
         for (int k = 0; k < g.nb; k++) {
-            if (!g.mem[k]->active) continue;
+            if (!g.mem[k]->active) { finish(*g.mem[k]); continue; }
             if (w != k) { std::memmove(g.th + (size_t)w * H, g.th + (size_t)k * H, sizeof(double) * H); g.mem[w] = g.mem[k]; }
             w++;
         }
         g.mem.resize(w);
+        // finished patients leave the host as well
+        owned.erase(std::remove_if(owned.begin(), owned.end(), [](const std::unique_ptr<Patient> &p) { return p->slot < 0; }), owned.end());
         return true;
     };
+    const auto t_loop0 = now();
     {
         std::deque<std::pair<int, int>> inflight;   // (group, lane), oldest first
         std::deque<int> ready;
         for (int g = 0; g < (int)groups.size(); g++) ready.push_back(g);
         int free_lanes[2] = {1, 1};
-        // Re-forming: groups are cut once, from the active set at the start; patients finish at different times (early stop of the
-        // variational-EM outer loop, ref: util/c_optimizer_varEM.cpp:89-95; line-search failures, ref: util/c_optimizer_scg.cpp:125-131),
-        // and once what is left fits ONE launch that no longer fills the chip twice over, two half-empty launches per step are
-        // slower than one.  When that point is reached nothing new is queued until the device is idle, then the groups are merged.
+        // Re-forming at the tail: once the list is exhausted patients only leave, and when what is left fits ONE launch that no longer
+        // fills the chip twice over, two half-empty launches per step are slower than one.  When that point is reached nothing new is
+        // queued until the device is idle, then the groups are merged.
         auto want_merge = [&]() {
+            if (!loader.exhausted()) return false;
             size_t act = 0, nonempty = 0;
             for (const Group &g : groups) { act += g.mem.size(); nonempty += g.mem.empty() ? 0 : 1; }
-            return nonempty >= 2 && (int)act <= max_batch && (int)act < 2 * std::max(1, pingpong_min);
+            return nonempty >= 2 && act <= bufcap && (int)act <= max_batch && (int)act < 2 * std::max(1, pingpong_min);
         };
         while (!ready.empty() || !inflight.empty()) {
             if (inflight.empty() && groups.size() > 1 && want_merge()) {
-                Group mg;
-                for (Group &g : groups) mg.mem.insert(mg.mem.end(), g.mem.begin(), g.mem.end());
-                const size_t cap = mg.mem.size();
-                mg.th = (double *)medgp_host_alloc(sizeof(double) * cap * H);
-                mg.nl = (double *)medgp_host_alloc(sizeof(double) * cap);
-                mg.gr = (double *)medgp_host_alloc(sizeof(double) * cap * H);
-                mg.st = (int32_t *)medgp_host_alloc(sizeof(int32_t) * cap);
-                if (!mg.th || !mg.nl || !mg.gr || !mg.st) { cout << "ERROR: pinned host allocation failed" << endl; return 1; }
-                size_t w = 0;
-                for (Group &g : groups) {   // the pending request rows travel with their patients
-                    if (!g.mem.empty()) std::memcpy(mg.th + w * H, g.th, sizeof(double) * g.mem.size() * H);
-                    w += g.mem.size();
-                    medgp_host_free(g.th); medgp_host_free(g.nl); medgp_host_free(g.gr); medgp_host_free(g.st);
+                Group &mg = groups[0];
+                size_t total = mg.mem.size();
+                for (size_t gi = 1; gi < groups.size(); gi++) {   // the pending request rows travel with their patients
+                    Group &g = groups[gi];
+                    if (!g.mem.empty()) std::memcpy(mg.th + total * H, g.th, sizeof(double) * g.mem.size() * H);
+                    mg.mem.insert(mg.mem.end(), g.mem.begin(), g.mem.end());
+                    total += g.mem.size();
+                    g.mem.clear();
                 }
-                cout << "INFO: " << groups.size() << " groups merged into one of " << cap << " active patients" << endl;
+                mg.cap = bufcap;
+                cout << "INFO: " << groups.size() << " groups merged into one of " << total << " active patients" << endl;
                 merges++;
-                groups.clear();
-                groups.push_back(std::move(mg));
+                for (size_t gi = 1; gi < groups.size(); gi++) { Group &g = groups[gi]; medgp_host_free(g.th); medgp_host_free(g.nl); medgp_host_free(g.gr); medgp_host_free(g.st); }
+                groups.resize(1);
                 ready.clear();
                 ready.push_back(0);
             }
-            while (!ready.empty() && (free_lanes[0] || free_lanes[1]) && !(groups.size() > 1 && !inflight.empty() && want_merge())) {
+            // queue a step of every group that is not in flight (at most one per lane); a group below its size takes new patients in first
+            size_t tries = ready.size();
+            while (tries-- > 0 && !ready.empty() && (free_lanes[0] || free_lanes[1]) && !(groups.size() > 1 && !inflight.empty() && want_merge())) {
                 const int g = ready.front(); ready.pop_front();
                 const int lane = free_lanes[0] ? 0 : 1;
                 const auto t0 = now();
+                // with nothing in flight the device is idle anyway: wait for the reader then (start of the run; everybody finished at once)
+                if (!refill(groups[g], inflight.empty())) return 1;
                 if (!submit(groups[g], lane)) return 1;
                 t_host += secs(t0, now());
-                if (groups[g].nb == 0) continue;          // every patient of the group is done
+                if (groups[g].nb == 0) {                  // nobody to evaluate
+                    if (!loader.exhausted()) ready.push_back(g);   // (the reader has nothing ready yet: asked again after the next wait)
+                    continue;                                      // list exhausted: this group is done for good
+                }
                 free_lanes[lane] = 0;
                 inflight.push_back({g, lane});
                 steps++;
             }
-            if (inflight.empty()) break;
+            if (inflight.empty()) {
+                if (loader.exhausted()) {
+                    bool any = false;
+                    for (const Group &g : groups) any = any || !g.mem.empty();
+                    if (!any) break;
+                }
+                continue;
+            }
             const auto pr = inflight.front(); inflight.pop_front();
             const auto t1 = now();
             if (medgp_wait(ctx, pr.second)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
@@ -401,23 +598,16 @@ static int train_main(int argc, const char *argv[]) {
     cout << "optimization finished: " << total_evals << " nlml+grad evaluations in " << steps << " lock-step batches" << endl;
     cout << "INFO: lock-step optimisation: " << t_loop << " s wall (" << t_wait << " s waiting for the device, " << t_host
          << " s in the host optimiser on " << pool.size() << " threads, " << groups_initial << " group(s)" << (merges ? ", merged into one when the active set had shrunk" : "") << ")" << endl;
+    cout << "INFO: continuous admission: " << n_finished << " patients through " << resident << " resident slots in " << admissions << " admissions ("
+         << t_admit << " s, of which screening " << t_screen << " s for " << screen_evals << " nlml-only evaluations); sizes from "
+         << (t_scan > 0 ? "the list / file headers in " : "") << t_scan << " s" << endl;
+    if (t_loop - t_admit > 0)
+        cout << "INFO: gradient evaluations per second of lock-step time outside admissions: " << (double)total_evals / (t_loop - t_admit)
+             << "; of the whole loop: " << (double)total_evals / t_loop << endl;
 
-    // ---------------- outputs (ref :297-323)
-    for (auto &pp : pts) {
-        Patient &p = *pp;
-        if (p.sample_flag && p.success) {
-            if (p.use_vem) { p.best_loss = p.vem.opt_loss; p.opt_parameter = p.vem.opt_parameter; }
-            else { p.best_loss = p.scg.opt_loss; p.opt_parameter = p.scg.opt_parameter; }
-            c_experiment::output_double_bin(curr_exp.get_exp_train_dir() + "train_hyp_" + p.PAN, p.opt_parameter);
-            if (curr_exp.get_prior_mode() == 2)
-                c_experiment::output_double_bin(curr_exp.get_exp_train_dir() + "train_var_hyp_" + p.PAN, p.prior.get_cov_varEM_all());
-        }
-        p.flag_data = p.sample_flag && p.success;
-        cout << "finish individual id: " << p.PAN << " w/ " << p.t.size() << " samples; flag = " << p.flag_data
-             << "; final loss = " << p.best_loss << endl;
-        c_experiment::output_int_txt(curr_exp.get_exp_train_dir() + "train_num_" + p.PAN, {(int)p.t.size()});
-        c_experiment::output_int_txt(curr_exp.get_exp_train_dir() + "train_flag_" + p.PAN, {(int)p.flag_data});
-    }
+    // ---------------- closing lines, list order (ref :297-323; the files were written when each patient finished)
+    for (size_t i = 0; i < pans.size(); i++) if (mine[i]) cout << final_line[i];
+    owned.clear();
     if (ctx) medgp_destroy(ctx);
     time_t t_end;
     time(&t_end);

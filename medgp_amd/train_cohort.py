@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """Cohort training across the GPUs of one node: one process per GPU (torch.distributed), no data-path collective --
 patients are independent; the reference fans them out as one scheduler job per patient and the scheduler balances them
-dynamically (ref: medgpc/util/run_exp_generator.py:213-260, scripts/slurm_della.json:6-62).  Every rank runs the lock-step
-trainer `medgp_train --pan-list <chunk> --device <local rank>`.
+dynamically (ref: medgpc/util/run_exp_generator.py:213-260, scripts/slurm_della.json:6-62).  Every rank runs ONE long-lived
+lock-step trainer `medgp_train --pan-list <list> --device <local rank>` (continuous admission: the trainer keeps --resident
+patients on its GPU and pulls the next one into every slot a finished patient frees, medgp_amd/host/medgp_train.cpp).
 
 Scheduling (--schedule):
-  dynamic (default)  the patient list is sorted by the cost model of medgp_amd.shard (N^3 + c Q N^2), longest first, and cut
-                     into chunks of --chunk patients (default 256 = one patient per CU); ranks PULL the next chunk from a shared
-                     counter (a flock-protected file in exp_train_dir: no process group exists while the trainers run).  The
-                     cost model cannot know how many evaluations a patient will take -- the variational-EM loop stops early on
-                     a relative loss change < 0.5 % (ref: util/c_optimizer_varEM.cpp:89-95), SCG line searches fail
-                     (ref: util/c_optimizer_scg.cpp:125-131) -- so a static partition leaves ranks idle behind the slowest
-                     shard; with a queue a rank that finishes early simply takes more chunks.
+  dynamic (default)  every rank's trainer is given the WHOLE list (with the observation counts, so that all of them walk it in the
+                     same order: longest patient first) and `--queue <file>`: the trainers PULL PATIENTS from one shared counter (a
+                     flock-protected file in exp_train_dir: no process group exists while the trainers run).  The cost model cannot
+                     know how many evaluations a patient will take -- the variational-EM loop stops early on a relative loss change
+                     < 0.5 % (ref: util/c_optimizer_varEM.cpp:89-95), SCG line searches fail (ref: util/c_optimizer_scg.cpp:125-131)
+                     -- so a static partition leaves ranks idle behind the slowest shard; with a queue a rank whose patients finish
+                     early simply takes more.  (Round 4 pulled chunks of 256 patients and started a trainer process per chunk: every
+                     chunk ended in small batches and paid 0.55 s of start-up.)  All ranks must be on one node (one file system lock).
   static             one LPT shard per rank, fixed before the first evaluation (rounds 1-3).
-A patient's results do not depend on which rank or chunk trained it (same kernels for the same batch-size class; pass
---pin-route to the trainer through --exe-args for bit-identity across batch-size classes as well).
+A patient's results do not depend on which rank trained it nor on who its batch-mates were, up to the last bits of the
+factorisation route (same kernels for the same batch-size class); pass --pin-route to the trainer through --exe-args for
+bit-identity across batch compositions as well.
 
 The ONE collective on data (optional, --gather): after training, the per-patient hyper vectors train_hyp_<PAN>.bin are
 all-gathered (RCCL over xGMI under the nccl backend, gloo on CPU) into <exp_train_dir>/cohort_train_hyp.npy --
@@ -27,6 +30,7 @@ import argparse
 import fcntl
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -67,11 +71,13 @@ def take_ticket(path):
         os.close(fd)
 
 
-def make_chunks(ns, chunk, Q):
-    """Patients longest-first (cost model of shard.cost, ties by index), cut into chunks of `chunk`."""
-    ns = np.asarray(ns)
-    order = np.lexsort((np.arange(ns.shape[0]), -shard.cost(ns, Q)))
-    return [order[i:i + chunk].tolist() for i in range(0, len(order), max(1, chunk))]
+def queue_path(train_dir):
+    """The shared patient counter of THIS launch: keyed on the launcher (its pid is the parent of every rank), the rendezvous port,
+    the elastic run id and the restart count -- workers restarted by torchrun (--max-restarts) get a fresh counter, not the
+    exhausted one of their previous life."""
+    key = "_".join(str(os.environ.get(k, "0")) for k in ("TORCHELASTIC_RUN_ID", "MASTER_PORT", "TORCHELASTIC_RESTART_COUNT"))
+    key = "".join(ch if ch.isalnum() or ch in "_-" else "-" for ch in key)
+    return os.path.join(train_dir, f".patient_queue_{key}_{os.getppid()}")
 
 
 def main(argv=None):
@@ -84,7 +90,8 @@ def main(argv=None):
     ap.add_argument("--backend", default=None, help="nccl (default with GPUs) or gloo")
     ap.add_argument("--max-batch", type=int, default=1024)
     ap.add_argument("--schedule", choices=("dynamic", "static"), default="dynamic")
-    ap.add_argument("--chunk", type=int, default=256, help="patients per work-queue chunk (dynamic schedule)")
+    ap.add_argument("--resident", type=int, default=1024, help="patients a trainer keeps on its GPU at once (continuous admission)")
+    ap.add_argument("--chunk", type=int, default=0, help="ignored (round 4's chunked queue); kept so that old command lines still parse")
     ap.add_argument("--timeout-hours", type=float, default=48.0,
                     help="process-group timeout: how long a finished rank waits for the slowest one")
     args = ap.parse_args(argv)
@@ -101,43 +108,44 @@ def main(argv=None):
     dist = None
 
     cfg = json.load(open(args.cfg))
-    pans = [p for p in open(args.pan_list).read().split() if p]
+    pans = [ln.split()[0] for ln in open(args.pan_list) if ln.strip()]     # (a second column, if any, is not trusted: counted below)
     ns = [count_observations(cfg, p) for p in pans]
     extra = args.exe_args.split()
 
-    def run_trainer(idx, tag):
+    def run_trainer(idx, tag, more=()):
+        """One trainer process on the patients `idx` (list file: PAN and observation count per line); returns (exit status, the
+        patients it finished -- with a shared queue that is only known afterwards)."""
         shard_file = os.path.join(cfg["exp_train_dir"], f"pan_{tag}.txt")
         with open(shard_file, "w") as f:
-            f.write("\n".join(pans[i] for i in idx) + "\n")
+            f.write("".join(f"{pans[i]} {ns[i]}\n" for i in idx))
         r = subprocess.run([args.exe, "--cfg", args.cfg, "--pan-list", shard_file, "--device", str(device),
-                            "--max-batch", str(args.max_batch)] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                            "--max-batch", str(args.max_batch), "--resident", str(args.resident)] + list(more) + extra,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         with open(os.path.join(cfg["exp_train_dir"], f"train_{tag}.log"), "w") as f:
             f.write(r.stdout)
-        return shard.exit_status(r.returncode)
+        index = {p: i for i, p in enumerate(pans)}
+        done = [index[m] for m in re.findall(r"^finish individual id: (\S+) w/", r.stdout, flags=re.M) if m in index]
+        return shard.exit_status(r.returncode), done
 
     rc = 0
     mine = []          # global indices of the patients this rank trained
     t_busy = 0.0
+    qfile = None
     if args.schedule == "static" or world == 1:
         parts = shard.lpt_partition(ns, world, Q=int(cfg["Q"]))
-        mine = [int(i) for i in parts[rank]]
-        if mine:
+        part = [int(i) for i in parts[rank]]
+        if part:
             t0 = time.perf_counter()
-            rc = run_trainer(mine, f"shard_rank{rank}")
+            rc, mine = run_trainer(part, f"shard_rank{rank}")
             t_busy = time.perf_counter() - t0
     else:
-        chunks = make_chunks(ns, args.chunk, int(cfg["Q"]))
-        # one counter per launch: all ranks of a node are children of the same launcher process
-        qfile = os.path.join(cfg["exp_train_dir"], f".chunk_queue_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
-        while True:
-            k = take_ticket(qfile)
-            if k >= len(chunks):
-                break
-            t0 = time.perf_counter()
-            rc = max(rc, run_trainer(chunks[k], f"chunk{k:04d}_rank{rank}"))
-            t_busy += time.perf_counter() - t0
-            mine += [int(i) for i in chunks[k]]
-        mine.sort()
+        if int(os.environ.get("LOCAL_WORLD_SIZE", world)) != world:
+            sys.exit("train_cohort: --schedule dynamic shares one counter file between the ranks of ONE node; use --schedule static across nodes")
+        qfile = queue_path(cfg["exp_train_dir"])
+        t0 = time.perf_counter()
+        rc, mine = run_trainer(list(range(len(pans))), f"queue_rank{rank}", ["--queue", qfile])
+        t_busy = time.perf_counter() - t0
+    mine = sorted(set(mine))
     with open(os.path.join(cfg["exp_train_dir"], f"train_rank{rank}.busy"), "w") as f:
         f.write(f"{t_busy:.6f} {len(mine)}\n")
     if world > 1:
@@ -184,11 +192,11 @@ def main(argv=None):
                 np.save(os.path.join(cfg["exp_train_dir"], "cohort_train_hyp.npy"), allrows)
         dist.barrier()
         dist.destroy_process_group()
-        if rank == 0 and args.schedule == "dynamic":
-            try:
-                os.remove(qfile)
-            except OSError:
-                pass
+    if rank == 0 and qfile:     # (after the barrier: every trainer has seen the exhausted counter)
+        try:
+            os.remove(qfile)
+        except OSError:
+            pass
     return rc
 
 

@@ -1,4 +1,4 @@
-"""GPU tests of the cohort launchers with the REAL hosts: medgp_amd.train_cohort (static shards vs the dynamic chunk queue) and
+"""GPU tests of the cohort launchers with the REAL hosts: medgp_amd.train_cohort (static shards vs the shared patient queue) and
 medgp_amd.test_cohort under torch.distributed.run with two gloo ranks that share the one GPU of the test box.  Patients are
 independent (ref: medgpc/util/run_exp_generator.py:213-260 fans them out as scheduler jobs), so whichever rank and chunk
 handles a patient, its files must be the same bytes as a single-process run."""
@@ -47,7 +47,7 @@ def test_train_and_test_cohort_launchers_two_ranks_one_gpu(tmp_path, built_lib):
     assert r.returncode == 0, r.stdout[-2000:]
     want = _files(exs["single"]["dirs"]["train"], "train_")
     assert len(want) == 6 * 4        # init hyp, hyp, num, flag per patient (prior mode 0: no var hyp)
-    for tag, extra, port in (("static", ["--schedule", "static"], 29561), ("dynamic", ["--schedule", "dynamic", "--chunk", "2"], 29563)):
+    for tag, extra, port in (("static", ["--schedule", "static"], 29561), ("dynamic", ["--schedule", "dynamic", "--resident", "2"], 29563)):
         _launch("medgp_amd.train_cohort", ["--cfg", exs[tag]["cfg"], "--pan-list", str(plist), "--backend", "gloo", "--gather"] + extra, port)
         got = _files(exs[tag]["dirs"]["train"], "train_")
         got = {k: v for k, v in got.items() if not k.endswith(".busy")}
@@ -57,7 +57,8 @@ def test_train_and_test_cohort_launchers_two_ranks_one_gpu(tmp_path, built_lib):
         allrows = np.load(os.path.join(exs[tag]["dirs"]["train"], "cohort_train_hyp.npy"))
         assert allrows.shape[0] == 6 and np.all(allrows[:, 1] == 1)
         busy = [open(os.path.join(exs[tag]["dirs"]["train"], f"train_rank{k}.busy")).read().split() for k in range(2)]
-        assert int(busy[0][1]) + int(busy[1][1]) == 6 and int(busy[0][1]) > 0 and int(busy[1][1]) > 0
+        # (the shared queue hands patients to whichever trainer asks first: with six tiny patients one rank may get most of them)
+        assert int(busy[0][1]) + int(busy[1][1]) == 6 and (tag == "dynamic" or (int(busy[0][1]) > 0 and int(busy[1][1]) > 0))
     # ---- the test launcher: mode kernel = one patient's trained hypers; two ranks vs one process
     mode = np.fromfile(os.path.join(exs["single"]["dirs"]["train"], "train_hyp_P001.bin"), np.float64)
     for tag in ("single", "static"):

@@ -77,13 +77,13 @@ def test_train_cohort_launcher_shards_and_gathers_over_gloo(tmp_path):
     for k, pan in enumerate(pans):
         exp = np.random.default_rng(zlib.crc32(pan.encode())).normal(size=H)
         assert np.array_equal(got[k, 2:], exp)
-    shards = [open(os.path.join(ex["dirs"]["train"], f"pan_shard_rank{r}.txt")).read().split() for r in range(2)]
+    shards = [[ln.split()[0] for ln in open(os.path.join(ex["dirs"]["train"], f"pan_shard_rank{r}.txt"))] for r in range(2)]
     assert sorted(shards[0] + shards[1]) == pans and shards[0] and shards[1]
 
 
 def test_train_cohort_dynamic_queue_balances_skewed_budgets_over_gloo(tmp_path):
-    """Ranks pull chunks of patients from a shared counter: with half of the patients ten times as expensive as the cost model
-    thinks (evaluation budgets are not known up front: early stops, failed line searches), both ranks stay busy to the end --
+    """Ranks pull patients from a shared counter (one long-lived trainer per rank): with half of the patients ten times as
+    expensive as the cost model thinks (evaluation budgets are not known up front: early stops, failed line searches), both ranks stay busy to the end --
     max / mean busy time <= 1.15 -- and the gathered result equals the static schedule's."""
     import shutil
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -102,7 +102,7 @@ def test_train_cohort_dynamic_queue_balances_skewed_budgets_over_gloo(tmp_path):
         out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                               "--master-addr", "127.0.0.1", "--master-port", port, "-m", "medgp_amd.train_cohort",
                               "--cfg", ex["cfg"], "--pan-list", str(plist), "--gather", "--backend", "gloo", "--schedule", schedule,
-                              "--chunk", "2", "--exe", os.path.join(ROOT, "tests", "gloo_train_cohort_worker.sh")],
+                              "--exe", os.path.join(ROOT, "tests", "gloo_train_cohort_worker.sh")],
                              env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert out.returncode == 0, out.stdout + out.stderr
         busy = [[float(v) for v in open(os.path.join(ex["dirs"]["train"], f"train_rank{r}.busy")).read().split()] for r in range(2)]
@@ -113,7 +113,17 @@ def test_train_cohort_dynamic_queue_balances_skewed_budgets_over_gloo(tmp_path):
     assert got.shape[0] == 32 and np.all(got[:, 1] == 1)
     t = np.array([b[0] for b in busy])
     assert t.max() / t.mean() <= 1.15, (busy, results["static"][1])
-    assert not any(f.startswith(".chunk_queue_") for f in os.listdir(ex["dirs"]["train"]))   # the counter is removed at the end
+    assert not any(f.startswith(".patient_queue_") for f in os.listdir(ex["dirs"]["train"]))   # the counter is removed at the end
+    # a trainer that dies on a signal (HIP fault -> SIGABRT, OOM kill -> SIGKILL: subprocess reports -9) must fail the WHOLE launch:
+    # the negative code used to lose against the healthy rank's 0 in all_reduce(MAX) (advisor finding, round 4)
+    for schedule, port in (("dynamic", "29555"), ("static", "29559")):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                              "--master-addr", "127.0.0.1", "--master-port", port, "-m", "medgp_amd.train_cohort",
+                              "--cfg", ex["cfg"], "--pan-list", str(plist), "--gather", "--backend", "gloo", "--schedule", schedule,
+                              "--exe", os.path.join(ROOT, "tests", "gloo_train_cohort_worker.sh")],
+                             env=dict(env, MEDGP_FAKE_UNIT="0", MEDGP_FAKE_KILL="P017"), capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert out.returncode != 0, (schedule, out.stdout[-500:])
+        assert not any(f.startswith(".patient_queue_") for f in os.listdir(ex["dirs"]["train"]))
 
 
 def test_test_cohort_launcher_cost_model_and_gloo_run(tmp_path):
@@ -166,3 +176,9 @@ def test_bench_refuses_ranks_that_share_a_gpu_under_nccl():
     nouuid = [mk(r, r, "") for r in range(2)]                             # a torch without the uuid property: device index stands in
     assert bench.check_ranks(nouuid, 2, "nccl") is None
     assert "share a GPU" in bench.check_ranks([mk(0, 0, ""), mk(1, 0, "")], 2, "nccl")
+
+
+def test_exit_status_of_a_signalled_child_is_positive():
+    assert shard.exit_status(0) == 0 and shard.exit_status(3) == 3
+    assert shard.exit_status(-9) == 137 and shard.exit_status(-6) == 134      # SIGKILL, SIGABRT: the shell's 128 + s
+    assert max(0, shard.exit_status(-11)) > 0

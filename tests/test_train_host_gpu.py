@@ -1,6 +1,7 @@
 """GPU test of medgp_train (the main_one_train replacement): file surface, lock-step cohort training ==
 one-patient-at-a-time training bit for bit, losses decrease, prior-mode-2 state is written."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -179,6 +180,42 @@ def test_train_pingpong_groups_and_host_threads_change_nothing(tmp_path, built_l
             for ex, _ in exs[1:]:
                 b = np.fromfile(os.path.join(ex["dirs"]["train"], name + pan + ".bin"), np.float64)
                 assert a.size > 0 and np.array_equal(a, b), (name, pan)
+
+
+@pytest.mark.parametrize("prior_index", [2, 0])
+def test_train_continuous_admission_matches_single_runs(tmp_path, built_lib, prior_index):
+    """Round 5: the trainer keeps --resident patients on the device and admits the next ones of the list into the slots that
+    finished patients free (screening + optimiser start while the others keep stepping).  Eleven patients through 3 resident slots
+    (and through 4 in two alternating groups, and 5 walked in list order, and with a shared work counter): every patient's files are
+    byte-identical to its single-patient run -- patients are independent (ref: one process per patient, main_one_train.cpp:41-324).
+    Sizes reach three 64-blocks, where the default factorisation route depends on the batch: --pin-route on both sides."""
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", HOST, "medgp_train"])
+    pans = [f"P{k:03d}" for k in range(11)]
+    Ns = [60, 150, 48, 3, 64, 33, 170, 75, 129, 52, 90]          # P003: too few samples, never takes a slot
+    opt = {"top_iteration_num": 6 if prior_index == 2 else 25}
+    ref = make_experiment(tmp_path / "ref", pans, D=2, Q=3, R=2, N=Ns, prior_index=prior_index, opt=opt)
+    for pan in pans:
+        run(["--cfg", ref["cfg"], "--pan", pan, "--thread", "1", "--pin-route"])
+    want = {f: open(os.path.join(ref["dirs"]["train"], f), "rb").read() for f in sorted(os.listdir(ref["dirs"]["train"]))}
+    assert len(want) == 10 * (5 if prior_index == 2 else 4) + 2
+    variants = (("a", ["--resident", "3"]), ("b", ["--resident", "4", "--pingpong-min", "2", "--host-threads", "3"]),
+                ("c", ["--resident", "5", "--order", "list", "--admit-min", "2"]), ("d", ["--resident", "2", "--queue", str(tmp_path / "q.cnt")]))
+    for tag, extra in variants:
+        ex = make_experiment(tmp_path / tag, pans, D=2, Q=3, R=2, N=Ns, prior_index=prior_index, opt=opt)
+        plist = tmp_path / f"pans_{tag}.txt"
+        plist.write_text("\n".join(pans) + "\n")
+        out = run(["--cfg", ex["cfg"], "--pan-list", str(plist), "--pin-route"] + extra)
+        m = re.search(r"continuous admission: (\d+) patients through (\d+) resident slots in (\d+) admissions", out)
+        assert m and int(m.group(1)) == 11 and int(m.group(2)) == int(extra[1]) and int(m.group(3)) >= 3, out[-1500:]
+        got = {f: open(os.path.join(ex["dirs"]["train"], f), "rb").read() for f in sorted(os.listdir(ex["dirs"]["train"]))}
+        assert sorted(got) == sorted(want), tag
+        for f in want:
+            assert got[f] == want[f], (tag, f)
+        # the closing lines come in list order whatever the walk order was
+        fin = re.findall(r"^finish individual id: (\S+) w/", out, flags=re.M)
+        assert fin == pans, (tag, fin)
+    assert int(open(tmp_path / "q.cnt").read()) >= 11          # the shared counter was walked to the end
 
 
 @pytest.mark.parametrize("kernel_index", [0, 8])
