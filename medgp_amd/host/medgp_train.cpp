@@ -133,8 +133,8 @@ class Loader {
 public:
     Loader(const c_experiment &ex_, const vector<string> &pans_, const vector<int> &order_, Tickets &tk_, size_t cap_, int nthreads)
         : ex(ex_), pans(pans_), order(order_), tk(tk_), cap(std::max<size_t>(cap_, 1)) {
-        for (int i = 0; i < std::max(1, nthreads); i++) th.emplace_back([this] { run(); });
-        live = (int)th.size();
+        live = std::max(1, nthreads);        // (before the first reader starts: a reader that finds the list exhausted decrements it)
+        for (int i = 0; i < live; i++) th.emplace_back([this] { run(); });
     }
     ~Loader() {
         { std::lock_guard<std::mutex> l(mu); stop = true; }

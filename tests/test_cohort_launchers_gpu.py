@@ -21,7 +21,7 @@ HOST = os.path.join(ROOT, "medgp_amd", "host")
 def _launch(module, args, port):
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), "-m", module] + args, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--master-port", str(port), "-m", module] + args, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return r
 
@@ -43,7 +43,7 @@ def test_train_and_test_cohort_launchers_two_ranks_one_gpu(tmp_path, built_lib):
     plist = tmp_path / "pans.txt"
     plist.write_text("\n".join(pans) + "\n")
     # one process, all patients: the reference result
-    r = subprocess.run([os.path.join(HOST, "medgp_train"), "--cfg", exs["single"]["cfg"], "--pan-list", str(plist)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([os.path.join(HOST, "medgp_train"), "--cfg", exs["single"]["cfg"], "--pan-list", str(plist)], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:]
     want = _files(exs["single"]["dirs"]["train"], "train_")
     assert len(want) == 6 * 4        # init hyp, hyp, num, flag per patient (prior mode 0: no var hyp)
@@ -67,7 +67,7 @@ def test_train_and_test_cohort_launchers_two_ranks_one_gpu(tmp_path, built_lib):
         open(os.path.join(fold_dir, "gmm_mode_mixture_num.txt"), "w").write(f"{Q}\n")
         mode.tofile(os.path.join(fold_dir, "gmm_mode_param.bin"))
     r = subprocess.run([os.path.join(HOST, "medgp_test"), "--cfg", exs["single"]["cfg"], "--pan-list", str(plist), "--fold", "0", "--kernclust-alg", "gmm"],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:]
     want = _files(exs["single"]["dirs"]["test"], "test_mean_")
     assert len(want) == 6 * 2 * 6

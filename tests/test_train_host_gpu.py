@@ -18,7 +18,7 @@ HOST = os.path.join(ROOT, "medgp_amd", "host")
 EXE = os.path.join(HOST, "medgp_train")
 
 
-def run(args, timeout=600):
+def run(args, timeout=180):
     r = subprocess.run([EXE] + args, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     return r.stdout
