@@ -189,10 +189,13 @@ private:
             }
             std::unique_lock<std::mutex> l(mu);
             inflight--;
-            if (p) ready.push_back(std::move(p));
-            else { live--; l.unlock(); cv_ready.notify_all(); return; }   // the list is exhausted (or the counter file failed)
+            const bool more = (bool)p;
+            if (more) ready.push_back(std::move(p));
+            else live--;                  // the list is exhausted (or the counter file failed)
             l.unlock();
             cv_ready.notify_all();
+            cv_space.notify_all();        // (a reader waiting for room must see that this one is no longer in flight)
+            if (!more) return;
         }
         std::lock_guard<std::mutex> l(mu);
         live--;
