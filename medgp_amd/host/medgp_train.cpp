@@ -133,8 +133,9 @@ class Loader {
 public:
     Loader(const c_experiment &ex_, const vector<string> &pans_, const vector<int> &order_, Tickets &tk_, size_t cap_, int nthreads)
         : ex(ex_), pans(pans_), order(order_), tk(tk_), cap(std::max<size_t>(cap_, 1)) {
-        live = std::max(1, nthreads);        // (before the first reader starts: a reader that finds the list exhausted decrements it)
-        for (int i = 0; i < live; i++) th.emplace_back([this] { run(); });
+        const int n = std::max(1, nthreads);
+        live = n;                            // (before the first reader starts: a reader that finds the list exhausted decrements it)
+        for (int i = 0; i < n; i++) th.emplace_back([this] { run(); });
     }
     ~Loader() {
         { std::lock_guard<std::mutex> l(mu); stop = true; }
