@@ -126,6 +126,15 @@ int medgp_set_priors(medgp_ctx *ctx, int nslots, const int32_t *slots, const uin
 int medgp_nlml_grad(medgp_ctx *ctx, int nbatch, const int32_t *slots, const double *theta, int flag_grad,
                     double *nlml, double *grad, int32_t *status);
 
+/* Random-initialisation screening: HOT LOOP A of the reference (ref: main_one_train.cpp:228-253 -- every one of the
+ * random_init_num hyper vectors evaluated on the patient, nlml only, the smallest wins).  The ninit vectors theta[ninit][H] are the same
+ * for every patient (c_experiment::get_global_hyp draws them once from the seed, ref: dataio/c_experiment.cpp:418-441), so they
+ * travel to the device ONCE per call and every (patient, vector) entry reads its row there; the nslots * ninit evaluations are
+ * queued in calls of at most max_batch entries without a host wait in between.  nlml / status: [nslots][ninit], host memory
+ * (status may be NULL).  Each evaluation is bit-identical to medgp_nlml_grad(flag_grad = 0) on the same (patient, vector) in a batch
+ * of the same composition. */
+int medgp_screen(medgp_ctx *ctx, int nslots, const int32_t *slots, int ninit, const double *theta, double *nlml, int32_t *status);
+
 /* Same operator with theta / nlml / grad / status in DEVICE memory of ctx's device, queued on the context's stream
  * (slots stays a host array: it only selects resident patients; it is copied before the call returns).  Asynchronous for
  * EVERY route: the one-workgroup-per-patient kernel runs the reference's jitter loop (ref: inference/c_inference_exact.cpp:

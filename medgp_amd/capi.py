@@ -22,7 +22,7 @@ SYMBOLS = [
     "medgp_abi_version", "medgp_device_count", "medgp_create", "medgp_destroy", "medgp_last_error",
     "medgp_num_hyp", "medgp_set_pi", "medgp_set_stream", "medgp_reserve", "medgp_set_patient",
     "medgp_set_patients", "medgp_set_prior", "medgp_set_priors", "medgp_host_alloc", "medgp_host_free", "medgp_nlml_grad_async",
-    "medgp_wait", "medgp_nlml_grad", "medgp_nlml_grad_device", "medgp_get_factor",
+    "medgp_wait", "medgp_nlml_grad", "medgp_screen", "medgp_nlml_grad_device", "medgp_get_factor",
     "medgp_factor", "medgp_factor_batch", "medgp_pin_route", "medgp_last_plan", "medgp_fit_predict", "medgp_fit_predict_batch", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
     "medgp_profile_kernel_name", "medgp_profile_read", "medgp_profile_reset", "medgp_kde_mode", "medgp_kde_mode_at",
 ]
@@ -81,6 +81,7 @@ def load():
     lib.medgp_nlml_grad_async.argtypes = [vp, C.c_int, C.c_int, i32p, vp, C.c_int, vp, vp, vp]
     lib.medgp_wait.argtypes = [vp, C.c_int]
     lib.medgp_nlml_grad.argtypes = [vp, C.c_int, i32p, dp, C.c_int, dp, dp, i32p]
+    lib.medgp_screen.argtypes = [vp, C.c_int, i32p, C.c_int, dp, dp, i32p]
     lib.medgp_nlml_grad_device.argtypes = [vp, C.c_int, i32p, vp, C.c_int, vp, vp, vp]
     lib.medgp_get_factor.argtypes = [vp, C.c_int, fp, fp, fp]
     lib.medgp_factor.argtypes = [vp, C.c_int, dp, dp, dp, i32p]
@@ -255,6 +256,17 @@ class Context:
     def pin_route(self, pinned=True):
         """medgp_pin_route: one factorisation kernel for every call, so a patient's bits do not depend on its batch-mates."""
         self._chk(self._lib.medgp_pin_route(self._h, 1 if pinned else 0))
+
+    def screen(self, slots, theta):
+        """medgp_screen: the hyper vectors theta [ninit, H] evaluated (nlml only) on every patient of slots. Returns (nlml, status),
+        both [len(slots), ninit]."""
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1, self.H)
+        ns, ni = slots.shape[0], theta.shape[0]
+        nlml = np.empty((ns, ni), dtype=np.float64)
+        st = np.empty((ns, ni), dtype=np.int32)
+        self._chk(self._lib.medgp_screen(self._h, ns, _ptr(slots, C.c_int32), ni, _ptr(theta, C.c_double), _ptr(nlml, C.c_double), _ptr(st, C.c_int32)))
+        return nlml, st
 
     def last_plan(self):
         """medgp_last_plan: [(entries, 64-blocks of the largest, route)] of the last nlml_grad call's size classes, largest first;

@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) k_prep(MedgpDev L, const double *__restri
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int slot = L.bslot[b];
     const int n = L.pn[slot];
-    const double *th = theta + (size_t)(L.bpos ? L.bpos[b] : b) * L.H;
+    const double *th = theta + (size_t)(L.tpos ? L.tpos[b] : (L.bpos ? L.bpos[b] : b)) * L.H;
     double *hyp = L.hyp + (size_t)b * L.hyp_stride;
     double *sig2 = hyp, *B = hyp + hyp_off_B(L), *w = hyp + hyp_off_w(L), *c = hyp + hyp_off_c(L);
     const int Q = L.Q, D = L.D, R = L.R;
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
         return;
     }
     const int slot = L.bslot[b], n = L.pn[slot];
-    const double *th = theta + (size_t)pos * H;
+    const double *th = theta + (size_t)(L.tpos ? L.tpos[b] : pos) * H;
     const double *hyp = L.hyp + (size_t)b * L.hyp_stride;
     const double *B = hyp + hyp_off_B(L);
     const double *S = L.S + (size_t)b * Q * D * D, *SM = L.SM + (size_t)b * Q * D * D, *SV = L.SV + (size_t)b * Q * D * D;

@@ -78,6 +78,10 @@ struct medgp_ctx {
     double *d_theta1 = nullptr, *d_nlml1 = nullptr, *d_grad1 = nullptr;
     int *d_status1 = nullptr;
     hipEvent_t ev_lane[2] = {nullptr, nullptr};
+    // copy streams of the asynchronous lanes: the theta upload of one lane and the result download of the other run beside the
+    // kernels on c->stream (on the compute stream they were 9 MB of PCIe traffic per 512-patient step, serialised with the kernels)
+    hipStream_t s_up = nullptr, s_down = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr};
     bool lane_pending[2] = {false, false};
     // pinned staging ring for small host-to-device uploads (slot tables, prior descriptors): the source of an asynchronous
     // copy must stay untouched until the copy has run, and nothing here waits for the device on the normal path
@@ -104,6 +108,10 @@ struct medgp_ctx {
     // cohort whose largest patient is far above the median: max_batch x max_n^2 would not fit 288 GB) they grow with the calls.
     size_t full_mat = 0, full_vec = 0, full_tab = 0, full_slab = 0, cap_mat = 0, cap_vec = 0, cap_tab = 0, cap_slab = 0;
     int *d_bpos = nullptr;
+    int *d_tpos = nullptr;          // theta rows of the entries (medgp_screen), internal order
+    bool tpos_on = false;
+    double *d_screen_theta = nullptr;   // the block of hyper vectors of medgp_screen
+    size_t screen_theta_cap = 0;
     bool last_has_inverse = false;   // the last pipeline run formed alpha and U = L^-T (medgp_get_factor is valid)
     // upload staging (one pinned host buffer + one device buffer, reused; guarded by ev_stage)
     char *h_stage = nullptr, *d_stage = nullptr;
@@ -338,6 +346,7 @@ MedgpDev class_view(const medgp_ctx *c, const SizeClass &k) {
     V.slab_stride = (size_t)3 * Q * V.slab_R * V.slab_C;
     V.bslot = L.bslot + b0;
     V.bpos = (c->plan.identity && c->plan.cls.size() == 1) ? nullptr : c->d_bpos + b0;
+    V.tpos = c->tpos_on ? c->d_tpos + b0 : nullptr;
     V.hyp = L.hyp + b0 * L.hyp_stride;
     V.cs = L.cs + k.off_tab; V.sn = L.sn + k.off_tab;
     V.Kmat = L.Kmat + k.off_mat; V.Linv = L.Linv + k.off_mat;
@@ -355,6 +364,7 @@ MedgpDev shifted_view(const MedgpDev &L, int b0) {
     const size_t ld = L.ldn, Q = L.Q, D = L.D;
     V.bslot = L.bslot + b0;
     if (L.bpos) V.bpos = L.bpos + b0;
+    if (L.tpos) V.tpos = L.tpos + b0;
     V.hyp = L.hyp + (size_t)b0 * L.hyp_stride;
     V.cs = L.cs + (size_t)b0 * Q * ld; V.sn = L.sn + (size_t)b0 * Q * ld;
     V.Kmat = L.Kmat + (size_t)b0 * ld * ld; V.Linv = L.Linv + (size_t)b0 * ld * ld;
@@ -739,6 +749,8 @@ void medgp_destroy(medgp_ctx *c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (hipStream_t st : {c->s_up, c->s_down}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (int i = 0; i < 2; i++) { if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]); if (c->ev_k[i]) (void)hipEventDestroy(c->ev_k[i]); }
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_bounce) (void)hipHostFree(c->h_bounce);
@@ -774,6 +786,7 @@ int medgp_synchronize(medgp_ctx *c) {
     if (!c) return MEDGP_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->s_down) HIPCHK(c, hipStreamSynchronize(c->s_down));   // (result downloads of the asynchronous lanes)
     return MEDGP_OK;
 }
 
@@ -804,6 +817,8 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     if ((rc = dalloc(c, &c->d_prior_on, S))) return rc;
     if ((rc = dalloc(c, &c->d_bslot, B))) return rc;
     if ((rc = dalloc(c, &c->d_bpos, B))) return rc;
+    if ((rc = dalloc(c, &c->d_tpos, B))) return rc;
+    c->d_screen_theta = nullptr; c->screen_theta_cap = 0; c->tpos_on = false;   // (freed by free_all above)
     if ((rc = dalloc(c, &c->d_status, B))) return rc;
     if ((rc = dalloc(c, &c->d_jit, B))) return rc;
     if ((rc = dalloc(c, &c->d_bn, B))) return rc;
@@ -821,6 +836,7 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     L.kidx = c->kidx; L.Q = c->Q; L.D = c->D; L.R = c->R; L.H = c->H; L.nlik = c->nlik;
     L.ldn = ldn; L.pld = ldn; L.max_slots = max_slots; L.max_batch = max_batch;
     L.bpos = nullptr;
+    L.tpos = nullptr;
     L.hyp_stride = (int)(D + Q * D * D + 2 * Q);
     L.pi = c->pi;
     L.dbg_fail = c->dbg_fail;
@@ -1126,6 +1142,8 @@ int medgp_nlml_grad(medgp_ctx *c, int nbatch, const int32_t *slots, const double
         if (status) std::memcpy(status, hs, sizeof(int32_t) * nbatch);
         return MEDGP_OK;
     }
+    // (this path shares lane 0's result staging: a download of that lane still in flight on the copy stream must have read it first)
+    if (c->lane_pending[0] && c->ev_lane[0]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane[0], 0));
     HIPCHK(c, hipMemcpyAsync(c->d_theta, theta, th_bytes, hipMemcpyHostToDevice, c->stream));
     int rc = medgp_nlml_grad_device(c, nbatch, slots, c->d_theta, flag_grad, c->d_nlml, c->d_grad, c->d_status_out);
     if (rc) return rc;
@@ -1133,6 +1151,78 @@ int medgp_nlml_grad(medgp_ctx *c, int nbatch, const int32_t *slots, const double
     if (want_grad) HIPCHK(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * nbatch * H, hipMemcpyDeviceToHost, c->stream));
     if (status) HIPCHK(c, hipMemcpyAsync(status, c->d_status_out, sizeof(int32_t) * nbatch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MEDGP_OK;
+}
+
+int medgp_screen(medgp_ctx *c, int nslots, const int32_t *slots, int ninit, const double *theta, double *nlml, int32_t *status) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (!slots || !theta || !nlml || nslots < 1 || ninit < 1) return fail(c, MEDGP_ERR_ARG, "medgp_screen: bad argument");
+    if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t H = c->H, total = (size_t)nslots * ninit;
+    for (int s = 0; s < nslots; s++)
+        if (slots[s] < 0 || slots[s] >= c->max_slots || c->h_n[slots[s]] < 0) return fail(c, MEDGP_ERR_ARG, "slots[%d] = %d is not a resident patient", s, slots[s]);
+    if ((size_t)ninit * H > c->screen_theta_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_screen_theta) { (void)hipFree(c->d_screen_theta); c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), (void *)c->d_screen_theta), c->allocs.end()); c->d_screen_theta = nullptr; }
+        int rc = dalloc(c, &c->d_screen_theta, (size_t)ninit * H);
+        if (rc) return rc;
+        c->screen_theta_cap = (size_t)ninit * H;
+    }
+    // (the result staging is lane 0's: a download of that lane still in flight on the copy stream must have read it first)
+    if (c->lane_pending[0] && c->ev_lane[0]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_lane[0], 0));
+    HIPCHK(c, hipMemcpyAsync(c->d_screen_theta, theta, sizeof(double) * ninit * H, hipMemcpyHostToDevice, c->stream));
+    // pinned landing area of all results: [nlml: total doubles | status: total ints]
+    const size_t land = sizeof(double) * total + sizeof(int32_t) * total;
+    if (land > c->bounce_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->h_bounce) (void)hipHostFree(c->h_bounce);
+        c->h_bounce = nullptr; c->bounce_cap = 0;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_bounce, land + land / 4, hipHostMallocDefault));
+        c->bounce_cap = land + land / 4;
+    }
+    double *hn = (double *)c->h_bounce;
+    int32_t *hs = (int32_t *)(c->h_bounce + sizeof(double) * total);
+    // chunks of consecutive (patient, init) entries: at most max_batch of them, and at most 48 GB of per-entry matrices
+    std::vector<int32_t> cs;
+    std::vector<int> tp;
+    size_t e0 = 0;
+    int rc = MEDGP_OK;
+    c->tpos_on = true;
+    while (e0 < total && rc == MEDGP_OK) {
+        cs.clear(); tp.clear();
+        long long bytes = 0;
+        size_t e = e0;
+        while (e < total && (int)cs.size() < c->max_batch) {
+            const int s = (int)(e / ninit), n = c->h_n[slots[s]];
+            const long long ld = (std::max(n, 1) + 63) / 64 * 64, per = 16 * ld * ld;
+            if (!cs.empty() && bytes + per > (48LL << 30)) break;
+            cs.push_back(slots[s]); tp.push_back((int)(e % ninit));
+            bytes += per; e++;
+        }
+        const int nb = (int)cs.size();
+        int max_n = 0;
+        if ((rc = set_batch(c, nb, cs.data(), &max_n, false, true))) break;
+        {   // theta rows in the plan's internal order
+            void *pin = nullptr;
+            if ((rc = pin_stage(c, sizeof(int) * nb, &pin))) break;
+            int *hp = (int *)pin;
+            for (int i = 0; i < nb; i++) hp[i] = tp[c->plan.order[i]];
+            hipError_t he = hipMemcpyAsync(c->d_tpos, hp, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream);
+            if (he != hipSuccess) { rc = fail(c, MEDGP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)); break; }
+        }
+        if ((rc = run_pipeline(c, nb, max_n, c->d_screen_theta, 0, false, 3, c->d_nlml, nullptr, c->d_status_out))) break;
+        hipError_t he = hipMemcpyAsync(hn + e0, c->d_nlml, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream);
+        if (he == hipSuccess) he = hipMemcpyAsync(hs + e0, c->d_status_out, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream);
+        if (he != hipSuccess) { rc = fail(c, MEDGP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)); break; }
+        e0 = e;
+    }
+    c->tpos_on = false;
+    c->last_nbatch = 0;   // (the cached plan carries this call's theta rows: the next call lays its own out)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (rc) return rc;
+    std::memcpy(nlml, hn, sizeof(double) * total);
+    if (status) std::memcpy(status, hs, sizeof(int32_t) * total);
     return MEDGP_OK;
 }
 
@@ -1156,14 +1246,25 @@ int medgp_nlml_grad_async(medgp_ctx *c, int lane, int nbatch, const int32_t *slo
     const size_t H = c->H;
     double *dth = lane ? c->d_theta1 : c->d_theta, *dnl = lane ? c->d_nlml1 : c->d_nlml, *dgr = lane ? c->d_grad1 : c->d_grad;
     int *dst = lane ? c->d_status1 : c->d_status_out;
-    HIPCHK(c, hipMemcpyAsync(dth, theta, sizeof(double) * nbatch * H, hipMemcpyHostToDevice, c->stream));
+    if (!c->s_up) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_down, hipStreamNonBlocking));
+    }
+    for (hipEvent_t *e : {&c->ev_up[lane], &c->ev_k[lane], &c->ev_lane[lane]})
+        if (!*e) HIPCHK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    // theta: on the upload stream (the lane's staging is free: the caller has waited for the lane's previous call)
+    HIPCHK(c, hipMemcpyAsync(dth, theta, sizeof(double) * nbatch * H, hipMemcpyHostToDevice, c->s_up));
+    HIPCHK(c, hipEventRecord(c->ev_up[lane], c->s_up));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_up[lane], 0));
     int rc = medgp_nlml_grad_device(c, nbatch, slots, dth, flag_grad, dnl, dgr, dst);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(nlml, dnl, sizeof(double) * nbatch, hipMemcpyDeviceToHost, c->stream));
-    if (flag_grad & MEDGP_FLAG_GRAD) HIPCHK(c, hipMemcpyAsync(grad, dgr, sizeof(double) * nbatch * H, hipMemcpyDeviceToHost, c->stream));
-    if (status) HIPCHK(c, hipMemcpyAsync(status, dst, sizeof(int32_t) * nbatch, hipMemcpyDeviceToHost, c->stream));
-    if (!c->ev_lane[lane]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_lane[lane], hipEventDisableTiming));
-    HIPCHK(c, hipEventRecord(c->ev_lane[lane], c->stream));
+    // results: on the download stream, behind this call's kernels
+    HIPCHK(c, hipEventRecord(c->ev_k[lane], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->s_down, c->ev_k[lane], 0));
+    HIPCHK(c, hipMemcpyAsync(nlml, dnl, sizeof(double) * nbatch, hipMemcpyDeviceToHost, c->s_down));
+    if (flag_grad & MEDGP_FLAG_GRAD) HIPCHK(c, hipMemcpyAsync(grad, dgr, sizeof(double) * nbatch * H, hipMemcpyDeviceToHost, c->s_down));
+    if (status) HIPCHK(c, hipMemcpyAsync(status, dst, sizeof(int32_t) * nbatch, hipMemcpyDeviceToHost, c->s_down));
+    HIPCHK(c, hipEventRecord(c->ev_lane[lane], c->s_down));
     c->lane_pending[lane] = true;
     return MEDGP_OK;
 }

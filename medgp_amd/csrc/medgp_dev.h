@@ -24,6 +24,8 @@ struct MedgpPrior {          // one hyper of one slot
 };
 
 struct MedgpDev {
+    const int *tpos;         // [nbatch] row of `theta` the entry reads, or null = its caller row (bpos): medgp_screen evaluates ONE block of
+                             // hyper vectors on many patients
     // family
     int kidx, Q, D, R, H, nlik;
     int ldn, max_slots, max_batch;   // ldn: leading dimension of THIS VIEW's batch buffers (a size class of the call: the class's largest n rounded up to 64)

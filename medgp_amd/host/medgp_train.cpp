@@ -220,7 +220,7 @@ private:
 
 static int train_main(int argc, const char *argv[]) {
     string exp_cfg, pan_arg, pan_list, queue_file, order_arg = "size";
-    int thread_num = 1, device = 0, max_batch = 1024, host_threads = 0, pingpong_min = 1024, resident = 1024, admit_min = -1, max_n_arg = 0;
+    int thread_num = 1, device = 0, max_batch = 1024, host_threads = 0, pingpong_min = 512, resident = 1024, admit_min = -1, max_n_arg = 0;
     bool pin_route = false;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--cfg") && i + 1 < argc) exp_cfg = argv[++i];
@@ -313,6 +313,8 @@ static int train_main(int argc, const char *argv[]) {
 
     vector<vector<double>> global_hyp_array;
     curr_exp.get_global_hyp(global_hyp_array);
+    vector<double> init_block;              // [ninit][H], contiguous: what medgp_screen uploads
+    for (const auto &v : global_hyp_array) init_block.insert(init_block.end(), v.begin(), v.end());
     const bool verbose = pans.size() == 1;   // the per-iteration lines of one patient; a cohort's state machines run on host threads
 
     // closing summary lines in list order (the reference prints one per process)
@@ -383,42 +385,26 @@ static int train_main(int argc, const char *argv[]) {
         if (admissions == 1) cout << "finish initialization of prior" << endl;
         {
             const auto ts0 = now();
-            vector<vector<double>> loss(live.size(), vector<double>(ninit, 0.0));
-            vector<vector<int32_t>> stat(live.size(), vector<int32_t>(ninit, 0));
-            vector<int32_t> slots;
-            vector<double> thetas, nl;
-            vector<int32_t> st;
-            vector<std::pair<int, int>> who;
-            long long bytes = 0;   // device matrices the queued entries need (two padded n x n fp64 matrices each): a call stays below 48 GB
-            auto flush = [&]() -> bool {
-                if (slots.empty()) return true;
-                nl.resize(slots.size()); st.resize(slots.size());
-                if (medgp_nlml_grad(ctx, (int)slots.size(), slots.data(), thetas.data(), 0, nl.data(), nullptr, st.data())) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
-                for (size_t k = 0; k < slots.size(); k++) { loss[who[k].first][who[k].second] = nl[k]; stat[who[k].first][who[k].second] = st[k]; }
-                screen_evals += (long long)slots.size();
-                slots.clear(); thetas.clear(); who.clear(); bytes = 0;
-                return true;
-            };
-            for (size_t s = 0; s < live.size(); s++) {
-                const long long ldp = ((long long)live[s]->t.size() + 63) / 64 * 64, per = 16 * ldp * ldp;
-                for (int init = 0; init < ninit; init++) {
-                    if (!slots.empty() && bytes + per > (48LL << 30) && !flush()) return false;
-                    slots.push_back(live[s]->slot);
-                    thetas.insert(thetas.end(), global_hyp_array[init].begin(), global_hyp_array[init].end());
-                    who.push_back({(int)s, init});
-                    bytes += per;
-                    if ((int)slots.size() == max_batch && !flush()) return false;
-                }
+            // one call: the ninit vectors are the same for every patient (ref: dataio/c_experiment.cpp:418-441), so they go to the device
+            // once and every (patient, vector) entry reads its row there (medgp_screen)
+            vector<double> loss_flat((size_t)live.size() * ninit);
+            vector<int32_t> stat_flat((size_t)live.size() * ninit);
+            vector<int32_t> slots(live.size());
+            for (size_t s = 0; s < live.size(); s++) slots[s] = live[s]->slot;
+            if (ninit > 0 && medgp_screen(ctx, (int)live.size(), slots.data(), ninit, init_block.data(), loss_flat.data(), stat_flat.data())) {
+                cout << "ERROR: " << medgp_last_error(ctx) << endl; return false;
             }
-            if (!flush()) return false;
+            screen_evals += (long long)live.size() * ninit;
+            auto loss = [&](size_t s, int init) { return loss_flat[s * ninit + init]; };
+            auto stat = [&](size_t s, int init) { return stat_flat[s * ninit + init]; };
             for (size_t s = 0; s < live.size(); s++) {
                 Patient &p = *live[s];
                 p.success = false;
                 for (int init = 0; init < ninit; init++) {
-                    const bool ok = stat[s][init] >= 0;
+                    const bool ok = stat(s, init) >= 0;
                     p.success = ok;
                     if (!ok) { cout << "WARNING: failed in computing objective!" << endl; break; }   // ref :243-246
-                    if (loss[s][init] < p.best_loss) { p.best_loss = loss[s][init]; p.best_init = global_hyp_array[init]; }
+                    if (loss(s, init) < p.best_loss) { p.best_loss = loss(s, init); p.best_init = global_hyp_array[init]; }
                 }
                 cout << "INFO: finish initialization " << ninit << " for " << p.PAN << "; best loss = " << p.best_loss << endl;
                 c_experiment::output_double_bin(curr_exp.get_exp_train_dir() + "train_init_hyp_" + p.PAN, p.best_init);
@@ -532,14 +518,16 @@ static int train_main(int argc, const char *argv[]) {
         std::deque<int> ready;
         for (int g = 0; g < (int)groups.size(); g++) ready.push_back(g);
         int free_lanes[2] = {1, 1};
-        // Re-forming at the tail: once the list is exhausted patients only leave, and when what is left fits ONE launch that no longer
-        // fills the chip twice over, two half-empty launches per step are slower than one.  When that point is reached nothing new is
-        // queued until the device is idle, then the groups are merged.
+        // Re-forming at the tail: once the list is exhausted patients only leave, and when what is left no longer fills the chip as ONE
+        // launch (fewer than --pingpong-min patients altogether), two quarter-full launches per step are slower than one.  When that point
+        // is reached nothing new is queued until the device is idle, then the groups are merged.  (Merging earlier -- round 4 merged at
+        // twice that size -- gives up the overlap of one group's state machines with the other group's evaluation for the whole tail:
+        // 2048 patients through 1024 slots spent half of the run in one merged group of 979.)
         auto want_merge = [&]() {
             if (!loader.exhausted()) return false;
             size_t act = 0, nonempty = 0;
             for (const Group &g : groups) { act += g.mem.size(); nonempty += g.mem.empty() ? 0 : 1; }
-            return nonempty >= 2 && act <= bufcap && (int)act <= max_batch && (int)act < 2 * std::max(1, pingpong_min);
+            return nonempty >= 2 && act <= bufcap && (int)act <= max_batch && (int)act < std::max(1, pingpong_min);
         };
         while (!ready.empty() || !inflight.empty()) {
             if (inflight.empty() && groups.size() > 1 && want_merge()) {

@@ -259,3 +259,54 @@ def test_set_priors_rejects_a_duplicate_slot():
     nl1, g1, _ = ctx.nlml_grad(np.arange(P), th, True)
     assert np.array_equal(nl0, nl1) and np.array_equal(g0, g1)
     ctx.close()
+
+
+def test_screen_equals_the_operator_and_the_oracle():
+    """medgp_screen (HOT LOOP A, ref: main_one_train.cpp:228-253): one block of hyper vectors evaluated on several patients.  Bit for
+    bit what medgp_nlml_grad(flag_grad = 0) gives for the same (patient, vector) entries in one call, the oracle's values to
+    tolerance, statuses included (a patient with n <= 2 fails, ref: util/c_objective_one.cpp:51); chunked calls (more entries than
+    max_batch) and calls while an asynchronous lane is in flight give the same bits."""
+    D, Q, R = 3, 2, 2
+    ns = [70, 2, 130, 33, 260]
+    pts = [synth.patient(61, p, D, n) for p, n in enumerate(ns)]
+    ninit = 7
+    th = np.stack([synth.theta(61, 100 + k, 7, Q, D, R) for k in range(ninit)])
+    ctx = medgp_amd.Context(7, Q, D, R)
+    ctx.reserve(len(ns), max(ns), len(ns) * ninit)
+    ctx.set_patients(np.arange(len(ns)), pts)
+    slots = np.array([4, 0, 1, 3, 2])
+    nl, st = ctx.screen(slots, th)
+    rep = np.repeat(slots, ninit)
+    nl_ref, _, st_ref = ctx.nlml_grad(rep, np.tile(th, (len(slots), 1)), False)
+    assert np.array_equal(st, st_ref.reshape(len(slots), ninit))
+    assert np.array_equal(nl, nl_ref.reshape(len(slots), ninit), equal_nan=True)
+    for a, s in enumerate(slots):
+        for k in range(ninit):
+            ref = O.nlml_grad(7, Q, D, R, *pts[s], th[k], flag_grad=False)
+            assert st[a, k] == ref["status"]
+            if ref["status"] == 0:
+                assert abs(nl[a, k] - ref["nlml"]) <= 1e-10 * abs(ref["nlml"])
+            else:
+                assert np.isnan(nl[a, k])
+    # chunked (max_batch 8 < 35 entries), pinned route on both sides: the bits do not depend on how the entries fall into calls
+    ctx.pin_route(True)
+    nl_p, st_p = ctx.screen(slots, th)
+    ctx2 = medgp_amd.Context(7, Q, D, R)
+    ctx2.reserve(len(ns), max(ns), 8)
+    ctx2.pin_route(True)
+    ctx2.set_patients(np.arange(len(ns)), pts)
+    nl2, st2 = ctx2.screen(slots, th)
+    assert np.array_equal(st2, st_p) and np.array_equal(nl2, nl_p, equal_nan=True)
+    # ... nor on an asynchronous lane being in flight (the screening shares lane 0's result staging)
+    H = th.shape[1]
+    lane_th = ctx.pinned((3, H), np.float64); lane_th[:] = th[:3]
+    lane_nl = ctx.pinned((3,), np.float64)
+    lane_gr = ctx.pinned((3, H), np.float64)
+    lane_st = ctx.pinned((3,), np.int32)
+    ctx.nlml_grad_async(0, np.array([0, 2, 4]), lane_th, True, lane_nl, lane_gr, lane_st)
+    nl3, st3 = ctx.screen(slots, th)
+    ctx.wait(0)
+    assert np.array_equal(nl3, nl_p, equal_nan=True) and np.array_equal(st3, st_p)
+    want_nl, want_gr, want_st = ctx.nlml_grad(np.array([0, 2, 4]), th[:3], True)
+    assert np.array_equal(lane_nl, want_nl) and np.array_equal(lane_gr, want_gr) and np.array_equal(lane_st, want_st)
+    ctx.close(); ctx2.close()
