@@ -488,11 +488,21 @@ int main(int argc, const char *argv[]) {
             p->n_all = (int)p->t.size();
             pts[i] = std::move(p);
         });
-        int n_max = 1;
-        for (auto &pp : pts) {
-            if (!pp->load_err.empty()) { cout << "ERROR: " << pp->load_err << endl; return 1; }
-            n_max = std::max(n_max, pp->n_all);
+        // A patient that cannot be read is reported and left out -- the reference runs one process per patient, so the others would
+        // still get their test_* files (ref: medgpc/util/run_exp_generator.py:213-260) -- and the run ends with a non-zero exit code.
+        int n_max = 1, n_unreadable = 0;
+        long long n_problems = 0;
+        {
+            vector<std::unique_ptr<TestPatient>> keep;
+            for (auto &pp : pts) {
+                if (!pp->load_err.empty()) { cout << "ERROR: " << pp->load_err << " (patient " << pp->PAN << " skipped)" << endl; n_unreadable++; continue; }
+                n_max = std::max(n_max, pp->n_all);
+                n_problems += pp->n_all;
+                keep.push_back(std::move(pp));
+            }
+            pts.swap(keep);
         }
+        if (pts.empty()) { cout << "ERROR: no readable patient" << endl; return 1; }
         if (pts.size() > 1)
             cout << "INFO: loaded " << pts.size() << " patients x " << curr_exp.get_feature_index().size() << " feature files in "
                  << ms_since(t_load0) << " ms on " << pool.size() << " host threads" << endl;
@@ -505,6 +515,8 @@ int main(int argc, const char *argv[]) {
         if (medgp_reserve(ctx, max_batch, n_max, max_batch)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
         if (medgp_pin_route(ctx, pin_route ? 1 : 0)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
 
+        time_t t1, t2;
+        time(&t1);   // (the total below includes the warm-up; the per-pass times do not)
         {   // first-use costs of the device (module load, first launches, staging growth) are not part of either pass
             const TestPatient *big = nullptr;
             for (auto &pp : pts) if (!big || pp->n_all > big->n_all) big = pp.get();
@@ -518,7 +530,7 @@ int main(int argc, const char *argv[]) {
             vector<double> Lw((size_t)t.size() * t.size()), zw(t.size());
             if (!t.empty()) (void)medgp_factor(ctx, 0, th0.data(), Lw.data(), zw.data(), &st0);
             if (!t.empty()) {   // a full-size batch of the per-problem path: grows the staging / scratch buffers once
-                const int nbw = max_batch;
+                const int nbw = (int)std::max<long long>(1, std::min<long long>(max_batch, n_problems));   // (never more problems than a pass has)
                 vector<int32_t> sl(nbw), pm, m2(nbw, m.empty() ? 0 : m[0]), stw(nbw);
                 vector<float> pt, py, t2w(nbw, t[0]), mw(nbw), vw(nbw);
                 vector<int64_t> off(1, 0);
@@ -533,8 +545,6 @@ int main(int argc, const char *argv[]) {
                     (void)medgp_fit_predict_batch(ctx, nbw, sl.data(), thw.data(), m2.data(), t2w.data(), mw.data(), vw.data(), stw.data());
             }
         }
-        time_t t1, t2;
-        time(&t1);
         const auto tw0 = std::chrono::steady_clock::now();
         bool ok = run_test_pass(curr_exp, ctx, pts, fold, false, "mean_wo_update", alg, test_kernel_param, max_batch, per_problem, pool);
         const double ms_wo = ms_since(tw0);
@@ -544,7 +554,8 @@ int main(int argc, const char *argv[]) {
         medgp_destroy(ctx);
         time(&t2);
         cout << "Finish all jobs. Total elapsed time = " << difftime(t2, t1) << " seconds" << endl;
-        return ok ? 0 : 1;
+        if (n_unreadable) cout << "ERROR: " << n_unreadable << " patient(s) could not be read" << endl;
+        return (ok && n_unreadable == 0) ? 0 : 1;
     } catch (const std::exception &e) {
         cout << "ERROR: " << e.what() << endl;
         return 1;

@@ -87,7 +87,7 @@ def test_online_imputation_matches_oracle_loop(tmp_path, built_lib):
     open(os.path.join(fold_dir, "gmm_mode_mixture_num.txt"), "w").write(f"{Q}\n")
     mode.tofile(os.path.join(fold_dir, "gmm_mode_param.bin"))
     r = subprocess.run([EXE, "--cfg", ex["cfg"], "--pan", "P007", "--thread", "1", "--fold", "0", "--kernclust-alg", "gmm",
-                        "--max-batch", "16"], capture_output=True, text=True, timeout=600)
+                        "--max-batch", "16"], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     m, t, y = loaded(ex, "P007", D)
     for flag_update, mode_name in ((False, "mean_wo_update"), (True, "mean_w_update")):
@@ -127,7 +127,7 @@ def test_cohort_list_is_byte_identical_to_one_run_per_patient(tmp_path, built_li
     plist = tmp_path / "pans.txt"
     plist.write_text("\n".join(pans) + "\n")
     base = [EXE, "--cfg", ex["cfg"], "--thread", "1", "--fold", "0", "--kernclust-alg", "gmm"]
-    r = subprocess.run(base + ["--pan-list", str(plist), "--max-batch", "64"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run(base + ["--pan-list", str(plist), "--max-batch", "64"], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "lock-step rounds" in r.stdout and "4 patient(s)" in r.stdout
     tdir = ex["dirs"]["test"]
@@ -137,12 +137,22 @@ def test_cohort_list_is_byte_identical_to_one_run_per_patient(tmp_path, built_li
     for f in cohort:
         os.remove(os.path.join(tdir, f))
     for pan in pans:
-        r1 = subprocess.run(base + ["--pan", pan, "--max-batch", "16"], capture_output=True, text=True, timeout=600)
+        r1 = subprocess.run(base + ["--pan", pan, "--max-batch", "16"], capture_output=True, text=True, timeout=240)
         assert r1.returncode == 0, r1.stdout[-3000:] + r1.stderr[-2000:]
     single = {f: open(os.path.join(tdir, f), "rb").read() for f in sorted(os.listdir(tdir)) if f.startswith("test_")}
     assert sorted(single) == sorted(cohort)
     for f in cohort:
         assert cohort[f] == single[f], f
+    # a patient of the list whose files cannot be read: reported, skipped, the others' files are the same bytes, exit code non-zero
+    # (the reference runs one process per patient, so one broken patient costs only its own outputs; advisor finding, round 4)
+    for f in cohort:
+        os.remove(os.path.join(tdir, f))
+    plist2 = tmp_path / "pans_missing.txt"
+    plist2.write_text("\n".join(pans[:2] + ["NOSUCH"] + pans[2:]) + "\n")
+    r2 = subprocess.run(base + ["--pan-list", str(plist2), "--max-batch", "64"], capture_output=True, text=True, timeout=240)
+    assert r2.returncode != 0 and "NOSUCH" in r2.stdout and "1 patient(s) could not be read" in r2.stdout
+    again = {f: open(os.path.join(tdir, f), "rb").read() for f in sorted(os.listdir(tdir)) if f.startswith("test_")}
+    assert again == cohort
     # and the cohort's values are the oracle loop's (the single-patient test above pins the arithmetic; here one more patient)
     m, t, y = loaded(ex, "P103", D)
     feat, ci, et, err, pred = reference_loop(m, t, y, mode, Q, D, R, True, 1e-4, 0.9, ex["feature_index"])
