@@ -50,6 +50,11 @@ struct MedgpDev {
     double *hyp;             // [batch][hyp_stride]: sig2[D] | B[Q*D*D] | w[Q] | c[Q]
     double *cs, *sn;         // [batch][Q][ldn]
     double *Kmat, *Linv;     // [batch][ldn*ldn]
+                             // INVARIANT for readers: only the LOWER triangle of Kmat (L) and the UPPER triangle of Linv (U = L^-T) are
+                             // defined after a factorisation.  The other halves hold leftovers (diag16 stores whole rows of a 16 x 16
+                             // tile, the look-ahead chain leaves stale X_k tiles): every consumer masks with column <= row (row <=
+                             // column for U) -- medgp_factor[_batch], medgp_get_factor, k_predict, k_wgrad.  tests/test_parity2_gpu.py
+                             // (test_exported_factors_have_exact_zero_triangles) holds the exports to it on both routes.
     double *z, *alpha;       // [batch][ldn]
     double *scal;            // [batch][4]: logdet, quad, -, -
     int *status;             // [batch]

@@ -470,3 +470,29 @@ def test_many_outputs_vs_oracle(D, Q, R, ns):
     np.testing.assert_allclose(mean, rp["mean"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(var, rp["var"], rtol=1e-5, atol=1e-6)
     ctx.close()
+
+
+@pytest.mark.parametrize("multi_cu", ["-1", "1"])
+def test_exported_factors_have_exact_zero_triangles(multi_cu, monkeypatch):
+    """The device buffers hold leftovers outside the triangle a factorisation defines (whole-row tile stores, stale chain tiles:
+    see MedgpDev::Kmat); every export must mask them.  Both routes (one workgroup per patient / look-ahead), through
+    medgp_factor_batch, medgp_factor and medgp_get_factor: the strict upper triangle is EXACTLY zero and L L^T = K."""
+    monkeypatch.setenv("MEDGP_MULTI_CU", multi_cu)
+    D, Q, R = 3, 2, 2
+    ns = [200, 70, 333, 129]
+    pts = [synth.patient(41, p, D, n, interleave=(p == 1)) for p, n in enumerate(ns)]
+    th = np.stack([synth.theta(41, p, 7, Q, D, R) for p in range(len(ns))])
+    ctx = make_ctx(7, Q, D, R, pts)
+    Ls, zs, st = ctx.factor_batch(np.arange(len(ns)), th, ns)
+    assert np.all(st == 0)
+    for p, (m, t, y) in enumerate(pts):
+        assert np.all(np.triu(Ls[p], 1) == 0.0)
+        K = O.gram(7, Q, D, R, m, t, th[p])               # (with the noise on the diagonal, caller order)
+        np.testing.assert_allclose(Ls[p] @ Ls[p].T, K, rtol=0, atol=1e-11 * np.abs(K).max())
+        L1, z1, s1 = ctx.factor(p, th[p], ns[p])
+        assert s1 == 0 and np.all(np.triu(L1, 1) == 0.0)
+    ctx.nlml_grad(np.arange(len(ns)), th, True)
+    for p in range(len(ns)):
+        alpha, linv, beta = ctx.get_factor(p, ns[p])
+        assert np.all(np.triu(linv, 1) == 0.0) and np.all(np.isfinite(linv))
+    ctx.close()
