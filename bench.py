@@ -349,6 +349,36 @@ def host_paths(out, dev_index, seed):
             "gradient_evaluations": int(m1.group(1)) if m1 else None, "lockstep_batches": int(m1.group(2)) if m1 else None,
             "lockstep_loop_s": float(m2.group(1)) if m2 else None, "device_wait_s": float(m2.group(2)) if m2 else None,
             "screening_evaluations": 20 * P, "output_files": nout}
+        # ---- f1 at the reference's REAL budget (scripts/opt_prior2.json:3-6: 1000 random initialisations, 40 variational-EM iterations of
+        #      30 SCG evaluations, early stop at < 0.5 % relative loss change, ref: util/c_optimizer_varEM.cpp:89-95): 2048 patients through
+        #      1024 resident slots of ONE long-lived trainer (continuous admission, round 5)
+        P2 = 2048
+        pans2 = [f"B{k:05d}" for k in range(P2)]
+        ex2 = make_experiment(os.path.join(tmp, "budget"), pans2, D=D, Q=Q, R=R, N=N, feature_index=tuple(range(D)), seed=seed + 5,
+                              opt=dict(random_init_num=1000, top_iteration_num=40, iteration_num_per_update=30))
+        plist2 = os.path.join(tmp, "budget_pans.txt")
+        open(plist2, "w").write("\n".join(pans2) + "\n")
+        t0 = time.perf_counter()
+        r = subprocess.run([os.path.join(host, "medgp_train"), "--cfg", ex2["cfg"], "--pan-list", plist2, "--device", str(dev_index)],
+                           capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError("medgp_train (real budget) rc %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:]))
+        m1 = re.search(r"optimization finished: (\d+) nlml\+grad evaluations in (\d+) lock-step batches", r.stdout)
+        m2 = re.search(r"lock-step optimisation: ([0-9.e+-]+) s wall \(([0-9.e+-]+) s waiting for the device", r.stdout)
+        m3 = re.search(r"continuous admission: (\d+) patients through (\d+) resident slots in (\d+) admissions \(([0-9.e+-]+) s, of which screening ([0-9.e+-]+) s for (\d+) nlml-only", r.stdout)
+        m4 = re.search(r"outside admissions: ([0-9.e+-]+); of the whole loop: ([0-9.e+-]+)", r.stdout)
+        out["train_cohort_2048xN512_D24_real_budget"] = {
+            "patients": P2, "N": N, "D": D, "random_init_num": 1000, "top_iteration_num": 40, "iteration_num_per_update": 30,
+            "process_wall_s": wall, "gradient_evaluations": int(m1.group(1)) if m1 else None, "lockstep_batches": int(m1.group(2)) if m1 else None,
+            "loop_s": float(m2.group(1)) if m2 else None, "device_wait_s": float(m2.group(2)) if m2 else None,
+            "resident_slots": int(m3.group(2)) if m3 else None, "admissions": int(m3.group(3)) if m3 else None,
+            "admission_s": float(m3.group(4)) if m3 else None, "screening_s": float(m3.group(5)) if m3 else None,
+            "screening_evaluations": int(m3.group(6)) if m3 else None,
+            "screening_evals_per_s": (int(m3.group(6)) / float(m3.group(5))) if m3 and float(m3.group(5)) > 0 else None,
+            "gradient_evals_per_s_outside_admissions": float(m4.group(1)) if m4 else None,
+            "gradient_evals_per_s_whole_loop": float(m4.group(2)) if m4 else None,
+            "output_files": len([f for f in os.listdir(ex2["dirs"]["train"]) if f.startswith("train_")])}
         # ---- f3: 64 test patients, D = 4, N 120 .. 200, both passes (with / without the online hyper updates)
         P, D, Q, R = 64, 4, 3, 2
         pans = [f"C{k:03d}" for k in range(P)]
