@@ -212,26 +212,9 @@ __device__ inline void prior_apply(const MedgpPrior &p, double hv, double pi, bo
 
 __device__ inline double sym_get(const double *S, int D, int d, int e) { return d >= e ? S[d * D + e] : S[e * D + d]; }
 
-// fused (round 5): the block sums are formed HERE from the slab pieces instead of by a k_slabsum launch in front -- S_q into the
-// LDS copy the dA_q dot products read anyway, the SM_q / SV_q bins inside the one contraction that consumes each of them once; the
-// same pieces are added in the same order (slab_bin_sum below = the loop of k_slabsum), so the bits do not change.  The host asks
-// for it when one workgroup owns all hypers of an entry and S_q, A fit the LDS copies (the headline shape: one launch and a 69 KB
-// round trip of S / SM / SV per entry less; k_slabsum + k_epilogue 88 us -> see DESIGN.md section 4.6).
-__device__ __forceinline__ double slab_bin_sum(const double *sl, int slab_C, const int *roff, const int *coff, const int *seg, int d, int e) {
-    double s = 0.0;
-    for (int rs = roff[d]; rs < roff[d + 1]; rs++) {
-        const int It = (seg[d] / 16 + (rs - roff[d])) / 4;
-        for (int cs = coff[e]; cs < coff[e + 1]; cs++) {
-            const int Jt = seg[e] / 64 + (cs - coff[e]);
-            if (Jt <= It) s += sl[(size_t)rs * slab_C + cs];
-        }
-    }
-    return s;
-}
-
 __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__restrict__ theta, int flag_grad, int from_slab,
                                                   double *__restrict__ nlml_out, double *__restrict__ grad_out,
-                                                  int *__restrict__ status_out, int fused) {
+                                                  int *__restrict__ status_out) {
     __shared__ double red2[MEDGP_EPI_PARTS][256];   // per-chunk partial sums of the prior log-density
     // LDS copies of S_q (all q) and of A for the Q D R gradients dA_q = S_q A_q (each a D-term dot product whose
     // operands otherwise come from global memory one dependent pair at a time); used when they fit
@@ -268,29 +251,8 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
     // diag(W): k_wgrad exports it; the v0 path keeps the full W in the Kmat buffer
     const double *Wd = from_slab ? L.wdiag + (size_t)b * ld : L.Kmat + (size_t)b * ld * ld;
     const size_t wds = from_slab ? 1 : (size_t)ld + 1;
-    __shared__ int s_roff[MEDGP_MAX_D + 1], s_coff[MEDGP_MAX_D + 1], s_seg[MEDGP_MAX_D + 1];
-    const double *slab = L.slab + (size_t)b * L.slab_stride;
-    const size_t plane = (size_t)L.slab_R * L.slab_C;
-    if (fused) {   // (the host sets it only with lds_sa's conditions and one part per entry)
-        for (int i = tid; i <= D; i += nt) {
-            s_roff[i] = L.proff[(size_t)slot * (D + 1) + i];
-            s_coff[i] = L.pcoff[(size_t)slot * (D + 1) + i];
-            s_seg[i] = seg[i];
-        }
-        __syncthreads();
-    }
     if (lds_sa) {
-        if (fused) {
-            const int nbins = D * (D + 1) / 2;
-            for (int idx = tid; idx < Q * nbins; idx += nt) {
-                const int q = idx / nbins;
-                int d, e;
-                tile_decode(idx - q * nbins, d, e);
-                s_S[q * D * D + d * D + e] = slab_bin_sum(slab + (size_t)q * plane, L.slab_C, s_roff, s_coff, s_seg, d, e);
-            }
-        } else {
-            for (int i = tid; i < Q * D * D; i += nt) s_S[i] = S[i];   // lower triangles are the ones sym_get reads
-        }
+        for (int i = tid; i < Q * D * D; i += nt) s_S[i] = S[i];   // lower triangles are the ones sym_get reads
         for (int i = tid; i < Q * D * R; i += nt) s_A[i] = th[D + i];
         __syncthreads();
     }
@@ -304,15 +266,13 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
         for (int w2 = tid >> 6; w2 < 2 * Q; w2 += nwave) {
             const int q = (w2 < Q) ? w2 : w2 - Q;
             const double *X = ((w2 < Q) ? SM : SV) + (size_t)q * D * D, *Bq = B + (size_t)q * D * D;
-            const double *Xsl = slab + (size_t)(((w2 < Q) ? 1 : 2) * Q + q) * plane;   // fused: the bins of this plane, each used once
             double sacc = 0.0;
             // (the bin index is decoded once and then advanced: tile_decode -- a double square root and two correction loops --
             //  per term was 26 of the 62 us this kernel took at D = 64; same terms in the same order)
             int d, e;
             tile_decode(lane, d, e);
             for (int idx = lane; idx < nbins; idx += 64) {
-                const double xv = fused ? slab_bin_sum(Xsl, L.slab_C, s_roff, s_coff, s_seg, d, e) : X[d * D + e];
-                sacc += ((d == e) ? 1.0 : 2.0) * Bq[d * D + e] * xv;
+                sacc += ((d == e) ? 1.0 : 2.0) * Bq[d * D + e] * X[d * D + e];
                 e += 64;
                 while (e > d) { e -= d + 1; d++; }
             }
@@ -399,7 +359,7 @@ __global__ void __launch_bounds__(256) k_epilogue(MedgpDev L, const double *__re
                     hv = exp(th[h]);
                     if (flag_grad) {
                         int kk = hc - Q * (D * R + 2), q = kk / D, d = kk - q * D;
-                        gv = 0.5 * hv * (fused ? s_S[q * D * D + d * D + d] : S[(size_t)q * D * D + d * D + d]);
+                        gv = 0.5 * hv * S[(size_t)q * D * D + d * D + d];
                     }
                 }
             }

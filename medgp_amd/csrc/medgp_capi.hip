@@ -142,7 +142,6 @@ struct medgp_ctx {
     int num_cu = 256;
     int dbg_fail = 0;         // MEDGP_DEBUG_FAIL_ATTEMPTS=k: test hook, see MedgpDev::dbg_fail
     int class_streams = kAuxStreams;   // MEDGP_CLASS_STREAMS=0: the size classes of a call run back to back on the call's stream (A-B)
-    int no_fused_epi = 0;     // MEDGP_NO_FUSED_EPILOGUE=1: k_slabsum + k_epilogue as two launches for every shape (A-B; same bits)
     int no_classes = 0;       // MEDGP_NO_CLASSES=1: rounds 1-4 behaviour -- one class per call, one route from its largest entry (A-B)
     hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
@@ -589,19 +588,17 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
             { Launcher l(c, KID_GRADBINS, stream); hipLaunchKernelGGL(k_gradbins_v0, dim3((nbins + 255) / 256, nbatch), dim3(256), 0, stream, L); }
         }
     }
-    // few entries: the hypers of an entry are spread over workgroups (H = 2954 at D = 64: 0.18 -> 0.07 ms for one entry); with a
-    // workgroup per CU anyway, one part per entry is faster (each part stages S and A again: 0.09 vs 0.20 ms at 512 entries)
-    const int nparts = (2 * nbatch >= c->num_cu) ? 1 : std::min(MEDGP_EPI_PARTS, (L.H + 255) / 256);
-    // one part per entry and S_q, A in its LDS copies: the epilogue adds the slab pieces itself (kernels_core.h), no k_slabsum launch
-    const bool fused = !c->no_fused_epi && nlml_dev && flag_grad && from_slab && nparts == 1 && L.kidx == 7 && L.Q * L.D * L.D <= 4096 && L.Q * L.D * L.R <= 1280 && 2 * L.Q <= 64;
-    if (flag_grad && from_slab && !fused) {
+    if (flag_grad && from_slab) {
         const int nbins3 = 3 * L.Q * tri(L.D);
         Launcher l(c, KID_EPILOGUE, stream);
         hipLaunchKernelGGL(k_slabsum, dim3(nbatch, (nbins3 + 255) / 256), dim3(256), 0, stream, L);
     }
     if (nlml_dev) {
         Launcher l(c, KID_EPILOGUE, stream);
-        hipLaunchKernelGGL(k_epilogue, dim3(nbatch, nparts), dim3(256), 0, stream, L, theta_dev, flag_grad, from_slab, nlml_dev, grad_dev, (int *)status_dev, fused ? 1 : 0);
+        // few entries: the hypers of an entry are spread over workgroups (H = 2954 at D = 64: 0.18 -> 0.07 ms for one entry); with a
+        // workgroup per CU anyway, one part per entry is faster (each part stages S and A again: 0.09 vs 0.20 ms at 512 entries)
+        const int nparts = (2 * nbatch >= c->num_cu) ? 1 : std::min(MEDGP_EPI_PARTS, (L.H + 255) / 256);
+        hipLaunchKernelGGL(k_epilogue, dim3(nbatch, nparts), dim3(256), 0, stream, L, theta_dev, flag_grad, from_slab, nlml_dev, grad_dev, (int *)status_dev);
     }
     HIPCHK(c, hipGetLastError());
     return MEDGP_OK;
@@ -728,7 +725,6 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     { const char *e = getenv("MEDGP_MULTI_CU"); c->force_mc = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_CLASS_STREAMS"); if (e) c->class_streams = std::max(0, std::min(kAuxStreams, atoi(e))); }
     { const char *e = getenv("MEDGP_NO_CLASSES"); c->no_classes = e ? atoi(e) : 0; }
-    { const char *e = getenv("MEDGP_NO_FUSED_EPILOGUE"); c->no_fused_epi = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_WGRAD_DEEP"); c->wgrad_deep = e ? std::max(1, atoi(e)) : -1; }
     { const char *e = getenv("MEDGP_DEBUG_FAIL_ATTEMPTS"); c->dbg_fail = e ? atoi(e) : 0; }
     for (int i = 0; i < kAuxStreams; i++) {

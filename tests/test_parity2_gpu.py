@@ -496,28 +496,3 @@ def test_exported_factors_have_exact_zero_triangles(multi_cu, monkeypatch):
         alpha, linv, beta = ctx.get_factor(p, ns[p])
         assert np.all(np.triu(linv, 1) == 0.0) and np.all(np.isfinite(linv))
     ctx.close()
-
-
-def test_fused_epilogue_gives_the_bits_of_the_two_launch_form(monkeypatch):
-    """Round 5: with one workgroup per entry the epilogue adds the slab pieces itself (no k_slabsum launch).  Same pieces, same order:
-    nlml and every gradient component are bit-identical to the two-launch form (MEDGP_NO_FUSED_EPILOGUE=1), with and without the prior,
-    ragged sizes, outputs that are never observed."""
-    D, Q, R, P = 24, 5, 8, 160                         # (2 P >= #CU: one part per entry -> the fused form)
-    rng = np.random.default_rng(12)
-    ns = [int(v) for v in rng.integers(5, 300, size=P)]
-    pts = [synth.patient(91, p, D, n) for p, n in enumerate(ns)]
-    th = np.stack([synth.theta(91, p, 7, Q, D, R, sparse_frac=0.3) for p in range(P)])
-    res = []
-    for env in (None, "1"):
-        if env:
-            monkeypatch.setenv("MEDGP_NO_FUSED_EPILOGUE", env)
-        ctx = make_ctx(7, Q, D, R, pts)
-        out = [ctx.nlml_grad(np.arange(P), th, True)]
-        ctx.set_prior(-1, *synth.hier_gamma_prior(Q, D, R, 0.01))
-        out.append(ctx.nlml_grad(np.arange(P), th, True))
-        res.append(out)
-        ctx.close()
-    for a, b in zip(res[0], res[1]):
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-    ref = O.nlml_grad(7, Q, D, R, *pts[3], th[3], prior=O.Prior.hier_gamma(Q, D, R, 0.01, 0.01), nthreads=4)
-    assert_parity(res[0][1][0][3], res[0][1][1][3], ref, "p3")
