@@ -483,7 +483,8 @@ def test_exported_factors_have_exact_zero_triangles(multi_cu, monkeypatch):
     pts = [synth.patient(41, p, D, n, interleave=(p == 1)) for p, n in enumerate(ns)]
     th = np.stack([synth.theta(41, p, 7, Q, D, R) for p in range(len(ns))])
     ctx = make_ctx(7, Q, D, R, pts)
-    Ls, zs, st = ctx.factor_batch(np.arange(len(ns)), th, ns)
+    LZ, st = ctx.factor_batch(np.arange(len(ns)), th, ns)
+    Ls = [lz[0] for lz in LZ]
     assert np.all(st == 0)
     for p, (m, t, y) in enumerate(pts):
         assert np.all(np.triu(Ls[p], 1) == 0.0)
