@@ -1,0 +1,39 @@
+"""profiles/<round>_pipe_budget.txt from profiles/<round>_pmc_summary.json: fp64 pipe time (MFMA issue + VALU issue) of every kernel
+of the headline step against its measured duration.  usage: python scratch/pipe_budget.py r05"""
+import json
+import sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+d = json.load(open(f"profiles/{rnd}_pmc_summary.json"))
+SIMDS, MFMA_CYC, VALU_CYC = 1024, 64, 4     # v_mfma_f64_16x16x4_f64 = 2048 flop at 32 flop / cycle / SIMD; one fp64 VALU instruction = 4 cycles
+rows, tot_pipe, tot_meas, clock = [], 0.0, 0.0, None
+for k, v in d.items():
+    dv = v.get("derived", {}) if k != "_meta" else {}
+    if "kernel_cycles" not in dv or k.startswith("k_scatter"):
+        continue
+    cyc = dv["kernel_cycles"]
+    mf = dv["mfma_f64_instructions"] * MFMA_CYC / SIMDS
+    va = dv["valu_wave_instructions"] * VALU_CYC / SIMDS
+    rows.append((k, cyc, mf, va, dv["mfma_busy_frac_of_1024_simds"], dv["wait_any_frac_of_wave_cycles"],
+                 dv.get("fetch_bytes_x2_if_wide_loads", 0) + dv.get("write_bytes", 0)))
+    tot_pipe += mf + va
+    tot_meas += cyc
+ghz = 2.4
+with open(f"profiles/{rnd}_pipe_budget.txt", "w") as f:
+    f.write(f"Pipe budget of the headline step (512 patients x N = 512, D = 24, Q = 5), from profiles/{rnd}_pmc_summary.json\n"
+            f"(device sources {d['_meta']['csrc_sha256'][:12]}, commit {d['_meta']['git_commit'][:7]}; per launch, averaged over the profiled launches).\n"
+            "Shader cycles per SIMD: MFMA issue = v_mfma_f64_16x16x4 count x 64 cycles / 1024 SIMDs (2048 flop at the 32 flop/cycle/SIMD of the\n"
+            "78.6 TFLOP/s peak; the SQ_VALU_MFMA_BUSY_CYCLES counter agrees: column `mfma busy`), VALU issue = SQ_INSTS_VALU x 4 cycles / 1024\n"
+            "(wave64 on 16 lanes; an upper bound for the non-fp64 part).  fp64 MFMA and fp64 VALU share the pipe (scratch/mfma_valu_overlap.hip),\n"
+            "so a kernel cannot be shorter than their SUM.  ms at 2.4 GHz.\n\n")
+    f.write(f"{'kernel':24s} {'measured':>10s} {'MFMA':>9s} {'VALU':>9s} {'pipe':>9s} {'pipe/meas':>9s} {'mfma busy':>9s} {'waves waiting':>13s} {'HBM GB':>8s}\n")
+    for k, cyc, mf, va, busy, wait, byt in rows:
+        f.write(f"{k[:24]:24s} {cyc / ghz / 1e6:9.3f}  {mf / ghz / 1e6:8.3f}  {va / ghz / 1e6:8.3f}  {(mf + va) / ghz / 1e6:8.3f}  {(mf + va) / cyc:8.3f}  {busy:8.3f}  {wait:12.3f}  {byt / 1e9:7.2f}\n")
+    f.write(f"{'step (sum of kernels)':24s} {tot_meas / ghz / 1e6:9.3f}  {'':8s}  {'':8s}  {tot_pipe / ghz / 1e6:8.3f}  {tot_pipe / tot_meas:8.3f}\n\n")
+    f.write("Reading: two thirds of the step is issue time of the fp64 pipe.  k_assemble_t and k_wgrad sit at 85 % / 79 % of it -- what is left\n"
+            "there is instruction count (14 of the 20 / 25 VALU instructions per pair and component are the fp64 exp2).  k_cholinv issues for 60 %\n"
+            "of its time: the rest is the serial path of a workgroup (64 pivots per panel on one wave, panel solve, panel init) that the second\n"
+            "workgroup on the CU only partly covers, and 5.1 GB of HBM traffic per launch (3.2 x the algorithmic 1.6 GB: left-looking history\n"
+            "re-reads).  Folding the assembly into its idle slots was priced in round 5 and costs four times what it saves\n"
+            f"(profiles/{rnd}_cholinv_fused_asm_price.txt).\n")
+print(open(f"profiles/{rnd}_pipe_budget.txt").read())
