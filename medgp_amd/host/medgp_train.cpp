@@ -153,6 +153,10 @@ public:
         cv_space.notify_all();
         return out;
     }
+    void set_cap(size_t c) {   // (smaller: readers finish what they hold and then wait)
+        { std::lock_guard<std::mutex> l(mu); cap = std::max<size_t>(c, 1); }
+        cv_space.notify_all();
+    }
     bool exhausted() {   // nothing ready and nothing will come
         std::lock_guard<std::mutex> l(mu);
         return ready.empty() && live == 0;
@@ -309,7 +313,10 @@ static int train_main(int argc, const char *argv[]) {
 
     Tickets tickets;
     tickets.path = queue_file;
-    Loader loader(curr_exp, pans, order, tickets, (size_t)std::max(2, resident / 8), std::max(1, std::min(4, host_threads / 2)));
+    // (read-ahead: the whole resident set while it is filled for the first time -- on all host threads, nothing else runs yet -- then an
+    //  eighth of it, set below once every group has been submitted once)
+    Loader loader(curr_exp, pans, order, tickets, (size_t)resident, std::max(1, host_threads));
+    bool filled = false;
 
     vector<vector<double>> global_hyp_array;
     curr_exp.get_global_hyp(global_hyp_array);
@@ -566,6 +573,7 @@ static int train_main(int argc, const char *argv[]) {
                 inflight.push_back({g, lane});
                 steps++;
             }
+            if (!filled && steps >= (long long)groups.size()) { loader.set_cap((size_t)std::max(2, resident / 8)); filled = true; }
             if (inflight.empty()) {
                 if (loader.exhausted()) {
                     bool any = false;
