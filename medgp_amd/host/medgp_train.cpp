@@ -162,6 +162,7 @@ public:
         return ready.empty() && live == 0;
     }
     long long taken() const { return n_taken.load(); }
+    bool failed() const { return counter_failed.load(); }
 
 private:
     void run() {
@@ -173,6 +174,7 @@ private:
                 inflight++;
             }
             const long long k = tk.take();
+            if (k < 0) counter_failed.store(true);   // the shared counter file could not be opened / locked / rewritten: the run must not end as a success
             std::unique_ptr<Patient> p;
             if (k >= 0 && k < (long long)order.size()) {
                 n_taken.fetch_add(1);
@@ -214,6 +216,7 @@ private:
     int live = 0;
     bool stop = false;
     std::atomic<long long> n_taken{0};
+    std::atomic<bool> counter_failed{false};
     std::deque<std::unique_ptr<Patient>> ready;
     std::mutex mu;
     std::condition_variable cv_ready, cv_space;
@@ -608,11 +611,13 @@ static int train_main(int argc, const char *argv[]) {
     // ---------------- closing lines, list order (ref :297-323; the files were written when each patient finished)
     for (size_t i = 0; i < pans.size(); i++) if (mine[i]) cout << final_line[i];
     owned.clear();
+    const bool counter_failed = loader.failed();
+    if (counter_failed) cout << "ERROR: the work counter " << queue_file << " could not be read or updated; patients of the list may be untrained" << endl;
     if (ctx) medgp_destroy(ctx);
     time_t t_end;
     time(&t_end);
     cout << "Finish all jobs. Total elapsed time = " << difftime(t_end, t_start) << " seconds" << endl;
-    return 0;
+    return counter_failed ? 1 : 0;
 }
 
 // exceptions of the host side (bad_alloc, a throwing loader on a worker thread: WorkPool rethrows them on the calling thread)
