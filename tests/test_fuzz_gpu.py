@@ -2,7 +2,8 @@
 shapes of test_parity_gpu.py do not reach -- outputs without any observation, an output whose observations all share one time
 stamp, a single component / rank one / more rank than the reference would configure, caller order shuffled, n from the
 reference's minimum (3, ref: util/c_objective_one.cpp:51) up to a few 64-blocks with ragged batches, on BOTH factorisation
-routes (one workgroup per patient and the multi-CU look-ahead schedule) and on the nlml-only path.
+routes (one workgroup per patient and the multi-CU look-ahead schedule), on the library's default routing (size classes with mixed
+routes) and on the nlml-only path.
 
 Tolerances as in test_parity_gpu.py (north_star: <= 1e-6 relative on log-lik and gradients).
 """
@@ -55,7 +56,7 @@ for c in range(24):
     CASES.append((c, D, Q, R, ns, mode))
 
 
-@pytest.mark.parametrize("route", ["wg", "la"])
+@pytest.mark.parametrize("route", ["wg", "la", "auto"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"c{c[0]}_D{c[1]}Q{c[2]}R{c[3]}_{c[5]}_n{'-'.join(map(str, c[4]))}")
 def test_random_shapes_vs_oracle(case, route, monkeypatch):
     c, D, Q, R, ns, mode = case
@@ -63,6 +64,8 @@ def test_random_shapes_vs_oracle(case, route, monkeypatch):
         if max(ns) <= 128:
             pytest.skip("the look-ahead schedule needs at least three 64-blocks")
         monkeypatch.setenv("MEDGP_MULTI_CU", "1")
+    elif route == "auto":      # default routing: size classes, each with its own route, on separate streams (round 5)
+        monkeypatch.delenv("MEDGP_MULTI_CU", raising=False)
     else:
         monkeypatch.setenv("MEDGP_MULTI_CU", "-1")
     g = np.random.Generator(np.random.Philox(key=[991, c]))

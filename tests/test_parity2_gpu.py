@@ -497,3 +497,27 @@ def test_exported_factors_have_exact_zero_triangles(multi_cu, monkeypatch):
         alpha, linv, beta = ctx.get_factor(p, ns[p])
         assert np.all(np.triu(linv, 1) == 0.0) and np.all(np.isfinite(linv))
     ctx.close()
+
+
+@pytest.mark.parametrize("fails", [1, 2])
+def test_jitter_retry_in_a_multi_class_call(fails, monkeypatch):
+    """The reference's retry loop (ref: c_inference_exact.cpp:99-111) inside a ragged call on DEFAULT routing: every size class runs
+    its own chain -- look-ahead classes hand the entries whose one attempt failed to their own k_cholinv<8,4>(sel = 2) launch, the
+    workgroup-per-patient classes retry in-kernel.  With the first `fails` attempts failed by construction every entry must report
+    status = fails and the values of K + (1 + fails) x noise (oracle at the shifted noise hypers), whatever its class and route."""
+    monkeypatch.setenv("MEDGP_DEBUG_FAIL_ATTEMPTS", str(fails))
+    D, Q, R = 3, 2, 2
+    ns = [700, 300, 130, 64, 40, 1000, 5, 210, 520]
+    pts = [synth.patient(55, p, D, n) for p, n in enumerate(ns)]
+    th = np.stack([synth.theta(55, p, 7, Q, D, R) for p in range(len(ns))])
+    ctx = make_ctx(7, Q, D, R, pts)
+    nlml, grad, st = ctx.nlml_grad(np.arange(len(ns)), th, True)
+    plan = ctx.last_plan()
+    assert len(plan) >= 4 and any(r == 2 for _, _, r in plan) and any(r != 2 for _, _, r in plan), plan
+    assert np.all(st == fails), st
+    for p, (m, t, y) in enumerate(pts):
+        ref = O.nlml_grad(7, Q, D, R, m, t, y, _theta_noise(th[p], D, fails), nthreads=4)
+        assert ref["status"] == 0
+        ref["grad"][:D] /= (1 + fails)          # the noise gradients use the ORIGINAL sigma (ref: c_inference_exact.cpp:194-202)
+        assert_parity(nlml[p], grad[p], ref, f"p{p} fails{fails}")
+    ctx.close()
