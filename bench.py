@@ -105,10 +105,10 @@ def check_ranks(seen, world, backend):
 
 def aggregate_time(t_local, world):
     """max over ranks of the local wall time (the driver's contract)."""
-    if world <= 1:
-        return float(t_local)
     import torch
     import torch.distributed as dist
+    if world <= 1 and not (dist.is_available() and dist.is_initialized()):
+        return float(t_local)
     if dist.get_backend() == "nccl":
         tt = torch.tensor([t_local], dtype=torch.float64, device="cuda")
     else:
@@ -505,7 +505,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count()
-    if world > 1:
+    # launched by torch.distributed.run (its environment is there): the process group is created even for ONE rank, so that a
+    # `--nproc-per-node 1` launch on a one-GPU box runs the very code path of the 8-GPU run -- RCCL initialisation, barrier, all-reduce,
+    # all-gather -- instead of leaving it untested (plain `python bench.py` has no such environment and no group)
+    use_dist = world > 1 or all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
+    if use_dist:
         import torch.distributed as dist
         backend = args.backend if args.backend != "auto" else ("nccl" if ndev >= world else "gloo")
         if backend == "nccl":   # the driver's case: one rank per GPU, RCCL over xGMI
@@ -552,7 +556,7 @@ def main():
         ctx.nlml_grad_device(slots, theta_d.data_ptr(), args.flag_grad, nlml_d.data_ptr(), grad_d.data_ptr(), stat_d.data_ptr())
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
 
@@ -612,7 +616,7 @@ def main():
     props = torch.cuda.get_device_properties(local_rank)
     me = {"rank": rank, "device": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
           "host": os.uname().nodename, "patients": int(P), "ms_per_step": 1e3 * t_local / max(args.steps, 1)}
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         seen = [None] * world
         dist.all_gather_object(seen, me)
@@ -626,7 +630,7 @@ def main():
         if rank == 0:
             print("bench.py: " + problem, file=sys.stderr, flush=True)
         ctx.close()
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         sys.exit(3)
 
@@ -687,7 +691,7 @@ def main():
                                "parallelism": f"patient-sharded x{world} (no collective)"})
         print(json.dumps(line), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -108,7 +108,9 @@ def main(argv=None):
         rc = shard.exit_status(r.returncode)
         with open(os.path.join(cfg["exp_test_dir"], f"test_fold{args.fold}_rank{rank}.log"), "w") as f:
             f.write(r.stdout)
-    if world > 1:
+    # MEDGP_FORCE_COLLECTIVES=1: also with ONE rank (under torch.distributed.run): lets a one-GPU box run the RCCL code path of the
+    # multi-GPU launch -- process group, all-reduce of the exit status, all-gather, barrier (tests/test_cohort_launchers_gpu.py)
+    if world > 1 or (os.environ.get("MEDGP_FORCE_COLLECTIVES") == "1" and "MASTER_ADDR" in os.environ):
         # created only now, after the shard has been processed (ranks can arrive far apart; see train_cohort.py)
         import datetime
         import torch

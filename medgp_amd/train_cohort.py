@@ -148,7 +148,9 @@ def main(argv=None):
     mine = sorted(set(mine))
     with open(os.path.join(cfg["exp_train_dir"], f"train_rank{rank}.busy"), "w") as f:
         f.write(f"{t_busy:.6f} {len(mine)}\n")
-    if world > 1:
+    # MEDGP_FORCE_COLLECTIVES=1: also with ONE rank (under torch.distributed.run): lets a one-GPU box run the RCCL code path of the
+    # multi-GPU launch -- process group, all-reduce of the exit status, all-gather, barrier (tests/test_cohort_launchers_gpu.py)
+    if world > 1 or (os.environ.get("MEDGP_FORCE_COLLECTIVES") == "1" and "MASTER_ADDR" in os.environ):
         # The process group is created only now, AFTER the training subprocess has returned: lock-step SCG runs until the
         # slowest patient of a shard finishes, so ranks can arrive hours apart, and a group created up front would have its
         # first collective (below) aborted by the default watchdog timeout (nccl 10 min).  The generous timeout covers the

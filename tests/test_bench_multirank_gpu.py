@@ -83,3 +83,25 @@ def test_backend_switch_and_nccl_refuses_shared_gpus(tmp_path):
     assert r.returncode != 0
     assert "needs one GPU per rank" in r.stderr + r.stdout
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_one_rank_under_torchrun_runs_the_rccl_path(tmp_path):
+    """The nccl (= RCCL) branch of bench.py on the one GPU of the test box: launched by torch.distributed.run with ONE rank the process
+    group is still created, so RCCL initialisation, the barriers, the max-time all-reduce on a device tensor and the all-gather of
+    `ranks_seen` all execute -- the code path of the driver's 2 / 4 / 8-GPU runs, which no test could reach before round 5.  Results
+    equal the plain single-process run bit for bit."""
+    plain, r0 = _run(1, ["--patients", "16"], str(tmp_path / "plain"))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dump = str(tmp_path / "tr")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--patients", "16", "--dump-results", dump] + COMMON
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["backend"] == "nccl" and line["n_gpus"] == 1 and len(line["ranks_seen"]) == 1
+    assert plain["backend"] == "none"
+    d = np.load(f"{dump}.rank0.npz")
+    for g, nl, gs, st in zip(d["gids"], d["nlml"], d["gsum"], d["status"]):
+        assert r0[int(g)] == (nl, gs, int(st))

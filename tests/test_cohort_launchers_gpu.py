@@ -76,3 +76,41 @@ def test_train_and_test_cohort_launchers_two_ranks_one_gpu(tmp_path, built_lib):
     assert sorted(got) == sorted(want)
     for f in want:
         assert got[f] == want[f], f
+
+
+def test_rccl_branches_with_one_rank(tmp_path, built_lib):
+    """The nccl (= RCCL) branches of the three launchers on the one GPU of the test box: ONE rank under torch.distributed.run with
+    MEDGP_FORCE_COLLECTIVES=1 creates the process group and runs the all-reduce of the exit status, the all-gather of the trained
+    hypers (train_cohort --gather), the padded all-gather of the KDE modes (cohort_mode) and the barriers on device tensors -- the
+    code the multi-GPU launch runs, which only gloo stand-ins reached before round 5."""
+    import torch
+    if torch.cuda.device_count() < 1:
+        pytest.skip("needs a GPU")
+    for exe in ("medgp_train", "medgp_test"):
+        if not os.path.exists(os.path.join(HOST, exe)):
+            subprocess.check_call(["make", "-s", "-C", HOST, exe])
+    pans = [f"P{k:03d}" for k in range(4)]
+    Q, D, R = 2, 2, 2
+    ex = make_experiment(tmp_path / "e", pans, D=D, Q=Q, R=R, N=[40, 66, 52, 30], prior_index=0, opt={"top_iteration_num": 8, "online_learn_rate": 1e-4})
+    plist = tmp_path / "pans.txt"
+    plist.write_text("\n".join(pans) + "\n")
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MEDGP_FORCE_COLLECTIVES="1")
+
+    def launch(args, port):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port)] + args, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        return r
+    launch(["-m", "medgp_amd.train_cohort", "--cfg", ex["cfg"], "--pan-list", str(plist), "--backend", "nccl", "--gather"], 29571)
+    rows = np.load(os.path.join(ex["dirs"]["train"], "cohort_train_hyp.npy"))
+    assert rows.shape[0] == 4 and np.all(rows[:, 1] == 1)
+    for k, pan in enumerate(pans):
+        assert np.array_equal(rows[k, 2:], np.fromfile(os.path.join(ex["dirs"]["train"], f"train_hyp_{pan}.bin"), np.float64))
+    fold_dir = os.path.join(ex["dirs"]["kernel"], "fold0")
+    os.makedirs(fold_dir)
+    open(os.path.join(fold_dir, "gmm_mode_mixture_num.txt"), "w").write(f"{Q}\n")
+    np.fromfile(os.path.join(ex["dirs"]["train"], "train_hyp_P001.bin"), np.float64).tofile(os.path.join(fold_dir, "gmm_mode_param.bin"))
+    launch(["-m", "medgp_amd.test_cohort", "--cfg", ex["cfg"], "--pan-list", str(plist), "--fold", "0", "--kernclust-alg", "gmm", "--backend", "nccl"], 29573)
+    assert open(os.path.join(ex["dirs"]["test"], "test_mean_w_update_flag_P002.txt")).read() == "1\n"
+    r = launch([os.path.join(ROOT, "tests", "rccl_cohort_mode_worker.py")], 29575)
+    assert "RCCL_COHORT_MODE_OK" in r.stdout
