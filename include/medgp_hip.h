@@ -80,7 +80,10 @@ int medgp_set_stream(medgp_ctx *ctx, void *hip_stream);
 
 /* (Re)allocate device storage: patient slots, largest padded n, largest batch per call.
  * Replaces the per-evaluation new[]/delete[] of N*N buffers, ref: core/gp_regression.cpp:102-117,
- * inference/c_inference_exact.cpp:66-68,168. Existing patients are discarded. */
+ * inference/c_inference_exact.cpp:66-68,168. Existing patients are discarded.
+ * The per-entry matrices (two padded n x n fp64 matrices per batch entry) are allocated here when max_batch x max_n^2 of them stay
+ * below 8 GB; beyond that (a cohort whose largest patient is far above the rest) they are grown by the calls to what their size
+ * classes need (see medgp_last_plan) -- a call that grows them waits for the device once and drops the factors of earlier calls. */
 int medgp_reserve(medgp_ctx *ctx, int max_slots, int max_n, int max_batch);
 
 /* Upload one patient (meta[i] in [0,D), t = time stamps, y = z-scored values; host pointers, copied).
