@@ -50,13 +50,14 @@ __global__ void __launch_bounds__(256) k_scatter_priors(const MedgpPrior *__rest
 // k* is one more right-hand side of the forward solve the factorisation already does for y: no inverse, no alpha.
 // Blocked forward substitution over the 64-wide panels: v_k = L_kk^-1 (k*_k - L[C_k, 0:64k] v[0:64k]); L_kk^-1 is the
 // diagonal block the factorisation leaves in Linv (stored as U_kk = L_kk^-T).  One workgroup per test point;
-// grid = (nstar, nbatch): test point js of problem b lives at index b * nstar + js of meta2 / t2 / mean / var.
+// grid = (nstar, entries of the class): test point js of the problem in caller row p lives at index p * nstar + js of meta2 / t2 / mean / var.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_predict(MedgpDev L, int nstar, const int *__restrict__ meta2, const double *__restrict__ t2,
                                                  double *__restrict__ vs_buf, float *__restrict__ mean, float *__restrict__ var) {
     __shared__ double red[256];
     __shared__ double rk[64];
-    const int b = blockIdx.y, js = b * nstar + blockIdx.x, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6;
+    // (b = entry of this size class's view; the test points, means and variances are indexed by the CALLER's row of the entry)
+    const int b = blockIdx.y, js = (L.bpos ? L.bpos[b] : b) * nstar + blockIdx.x, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, w = tid >> 6;
     const int slot = L.bslot[b], n = L.pn[slot], ld = L.ldn, Q = L.Q, D = L.D, npad = medgp_roundup(n, 64);
     if (L.status[b] < 0) {
         if (tid == 0) { mean[js] = __builtin_nanf(""); var[js] = __builtin_nanf(""); }
@@ -68,7 +69,7 @@ __global__ void __launch_bounds__(256) k_predict(MedgpDev L, int nstar, const in
     const int *meta = L.pmeta + (size_t)slot * L.pld;
     const double *zz = L.z + (size_t)b * ld;
     const double *Lm = L.Kmat + (size_t)b * ld * ld, *U = L.Linv + (size_t)b * ld * ld;
-    double *v = vs_buf + (size_t)js * ld;
+    double *v = vs_buf + (size_t)js * L.pld;   // (work rows at the context's stride: the classes of a call have different leading dimensions)
     const int ms = meta2 ? meta2[js] : 0;
     const double ts = t2[js];
     for (int i = tid; i < npad; i += nt) {

@@ -46,7 +46,6 @@ struct SizeClass {
     int route = ROUTE_WG84;    // last route taken (diagnostics: medgp_debug_plan)
 };
 struct BatchPlan {
-    bool sorted = false;       // false: the legacy layout -- one class, caller order, leading dimension = the context's (predict / factor exports)
     bool identity = true;      // internal order == caller order
     std::vector<int> order;    // internal index -> caller index
     std::vector<int> inv;      // caller index -> internal index
@@ -101,7 +100,6 @@ struct medgp_ctx {
     std::vector<uint8_t> h_perm_identity;
     std::vector<int> h_bslot;       // effective slots of the last call, CALLER order
     int last_nbatch = 0;
-    bool last_sorted = false;
     BatchPlan plan;                 // of the last call
     // arenas of the per-entry buffers (Kmat | Linv, z | alpha | wdiag, cs | sn, slab): what medgp_reserve's capacities would need at
     // most (full_*), what is allocated (cap_*).  Up to kArenaEager bytes they are allocated by medgp_reserve; beyond that (a ragged
@@ -274,8 +272,7 @@ inline long long wg_cost(int nb) { return (long long)nb * nb * (nb + 17); }
 
 // Select the batch and lay out its plan.  caller_order: entries whose patient was not uploaded grouped by output use the caller-order
 // copy of the patient (slot + max_slots), so that the factor is the one the caller's order defines (no gradient on that copy).
-// sorted: the operator's layout (size classes, see BatchPlan); otherwise the legacy one-class layout the exports read.
-int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bool caller_order = false, bool sorted = false) {
+int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bool caller_order = false) {
     if (nbatch < 1 || nbatch > c->max_batch) return fail(c, MEDGP_ERR_CAPACITY, "nbatch %d outside [1, %d]", nbatch, c->max_batch);
     int mx = 0;
     std::vector<int> eff(nbatch);
@@ -286,16 +283,15 @@ int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bo
         eff[b] = (caller_order && !c->h_perm_identity[s]) ? s + c->max_slots : s;
     }
     *max_n_out = mx;
-    bool same = (nbatch == c->last_nbatch) && sorted == c->last_sorted && std::memcmp(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch) == 0;
+    bool same = (nbatch == c->last_nbatch) && std::memcmp(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch) == 0;
     if (same) return MEDGP_OK;
     std::memcpy(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch);
     BatchPlan &P = c->plan;
-    P.sorted = sorted;
     P.order.resize(nbatch); P.inv.resize(nbatch); P.en.resize(nbatch);
     P.cls.clear();
     for (int b = 0; b < nbatch; b++) P.order[b] = b;
     auto nof = [&](int b) { return c->h_n[slots[b]]; };
-    const bool classes = sorted && !c->no_classes;
+    const bool classes = !c->no_classes;
     // by 64-block count, largest first (what the hardware dispatches first runs longest: LPT inside every launch); ties keep the caller's order
     if (classes) std::stable_sort(P.order.begin(), P.order.end(), [&](int a, int b) { return blocks64(nof(a)) > blocks64(nof(b)); });
     P.identity = true;
@@ -310,7 +306,7 @@ int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bo
         while (j < nbatch && (!classes || size_bucket(blocks64(P.en[j])) == bk)) { k.tsum += wg_cost(blocks64(P.en[j])); k.nbmax = std::max(k.nbmax, blocks64(P.en[j])); j++; }
         if (!classes) k.nbmax = blocks64(mx);
         k.count = j - i;
-        k.ld = sorted ? 64 * k.nbmax : c->ldn;
+        k.ld = 64 * k.nbmax;
         k.off_mat = om; k.off_vec = ov; k.off_tab = ot; k.off_slab = os;
         om += (size_t)k.count * k.ld * k.ld; ov += (size_t)k.count * k.ld; ot += (size_t)k.count * Q * k.ld;
         os += (size_t)k.count * 3 * Q * (k.ld / 16 + D) * (k.ld / 64 + D);
@@ -332,7 +328,6 @@ int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bo
         HIPCHK(c, hipMemcpyAsync(c->d_bpos, hp + nbatch, sizeof(int) * nbatch, hipMemcpyHostToDevice, c->stream));
     }
     c->last_nbatch = nbatch;
-    c->last_sorted = sorted;
     return MEDGP_OK;
 }
 
@@ -1100,7 +1095,7 @@ int medgp_nlml_grad_device(medgp_ctx *c, int nbatch, const int32_t *slots, const
     int max_n = 0, rc;
     // factor wanted but no gradient: patients that were not uploaded grouped by output are evaluated in the CALLER's order,
     // so that L^-1 is the factor the reference would hand to GP_Regression::predict (ref: core/gp_regression.cpp:181-196)
-    if ((rc = set_batch(c, nbatch, slots, &max_n, keep && !grad, true))) return rc;
+    if ((rc = set_batch(c, nbatch, slots, &max_n, keep && !grad))) return rc;
     return run_pipeline(c, nbatch, max_n, theta_dev, grad, keep, 3, nlml_dev, grad_dev, status_dev);
 }
 
@@ -1202,7 +1197,7 @@ int medgp_screen(medgp_ctx *c, int nslots, const int32_t *slots, int ninit, cons
         }
         const int nb = (int)cs.size();
         int max_n = 0;
-        if ((rc = set_batch(c, nb, cs.data(), &max_n, false, true))) break;
+        if ((rc = set_batch(c, nb, cs.data(), &max_n, false))) break;
         {   // theta rows in the plan's internal order
             void *pin = nullptr;
             if ((rc = pin_stage(c, sizeof(int) * nb, &pin))) break;
@@ -1365,7 +1360,7 @@ static int fit_predict_impl(medgp_ctx *c, int nbatch, const int32_t *slots, cons
     int max_n = 0, rc;
     // patients are used in the caller's order when that differs from the grouped one?  No: mean / var are permutation
     // invariant, the grouped copy serves.
-    if ((rc = set_batch(c, nbatch, slots, &max_n))) return rc;
+    if ((rc = set_batch(c, nbatch, slots, &max_n, false))) return rc;
     std::vector<double> ht2(ntot);
     std::vector<int> hm2(ntot, 0);
     for (int j = 0; j < ntot; j++) {
@@ -1380,15 +1375,17 @@ static int fit_predict_impl(medgp_ctx *c, int nbatch, const int32_t *slots, cons
     HIPCHK(c, hipMemcpyAsync(c->d_meta2, hm2.data(), sizeof(int) * ntot, hipMemcpyHostToDevice, c->stream));
     // factor + z = L^-1 y only (no inverse): k* rides along as one more right-hand side in k_predict
     if ((rc = run_pipeline(c, nbatch, max_n, c->d_theta, 0, false, 1, nullptr, nullptr, nullptr, true))) return rc;
-    {
+    for (const SizeClass &k : c->plan.cls) {   // (behind the join of the classes' chains: one launch per class view)
         Launcher l(c, KID_PREDICT);
-        hipLaunchKernelGGL(k_predict, dim3(nstar, nbatch), dim3(256), 0, c->stream, c->dev, nstar, c->d_meta2, c->d_t2, c->d_ks, c->d_mean, c->d_var);
+        hipLaunchKernelGGL(k_predict, dim3(nstar, k.count), dim3(256), 0, c->stream, class_view(c, k), nstar, c->d_meta2, c->d_t2, c->d_ks, c->d_mean, c->d_var);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(mean, c->d_mean, sizeof(float) * ntot, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(var, c->d_var, sizeof(float) * ntot, hipMemcpyDeviceToHost, c->stream));
-    if (status) HIPCHK(c, hipMemcpyAsync(status, c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int> st(nbatch, 0);
+    if (status) HIPCHK(c, hipMemcpyAsync(st.data(), c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (status) for (int i = 0; i < nbatch; i++) status[c->plan.order[i]] = st[i];   // internal order -> the caller's
     return MEDGP_OK;
 }
 
@@ -1399,14 +1396,20 @@ int medgp_factor_batch(medgp_ctx *c, int nbatch, const int32_t *slots, const dou
     if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
     HIPCHK(c, hipSetDevice(c->device));
     int max_n = 0, rc;
-    if ((rc = set_batch(c, nbatch, slots, &max_n, true))) return rc;       // the CALLER's observation order
-    const int ld = c->ldn;
+    if ((rc = set_batch(c, nbatch, slots, &max_n, true))) return rc;       // the CALLER's observation order; size classes
     HIPCHK(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * c->H * nbatch, hipMemcpyHostToDevice, c->stream));
     if ((rc = run_pipeline(c, nbatch, max_n, c->d_theta, 0, false, 1, nullptr, nullptr, nullptr, false))) return rc;
     std::vector<int> st(nbatch, 0);
-    HIPCHK(c, hipMemcpyAsync(st.data(), c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        std::vector<int> sti(nbatch, 0);
+        HIPCHK(c, hipMemcpyAsync(sti.data(), c->d_status, sizeof(int) * nbatch, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < nbatch; i++) st[c->plan.order[i]] = sti[i];   // internal order -> the caller's
+    }
     if (status) for (int b = 0; b < nbatch; b++) status[b] = st[b];
+    // every entry's rows of the batch buffers (its size class's view) and leading dimension
+    std::vector<MedgpDev> ev(nbatch);
+    for (int b = 0; b < nbatch; b++) ev[b] = entry_view(c, b);
     // export: the n x ld leading rows of every successful entry, through the pinned bounce buffer in groups of <= 256 MB
     size_t b0 = 0;
     while (Lout && b0 < (size_t)nbatch) {
@@ -1414,7 +1417,7 @@ int medgp_factor_batch(medgp_ctx *c, int nbatch, const int32_t *slots, const dou
         std::vector<size_t> off;
         while (b1 < (size_t)nbatch) {
             const int n = c->h_n[slots[b1]];
-            const size_t need = (st[b1] >= 0 && Lout[b1] && n > 0) ? sizeof(double) * n * ld : 0;
+            const size_t need = (st[b1] >= 0 && Lout[b1] && n > 0) ? sizeof(double) * n * ev[b1].ldn : 0;
             if (b1 > b0 && bytes + need > ((size_t)256 << 20)) break;
             off.push_back(bytes); bytes += need; b1++;
         }
@@ -1427,13 +1430,14 @@ int medgp_factor_batch(medgp_ctx *c, int nbatch, const int32_t *slots, const dou
         for (size_t b = b0; b < b1; b++) {
             const int n = c->h_n[slots[b]];
             if (st[b] >= 0 && Lout[b] && n > 0)
-                HIPCHK(c, hipMemcpyAsync(c->h_bounce + off[b - b0], c->dev.Kmat + b * (size_t)ld * ld, sizeof(double) * n * ld, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->h_bounce + off[b - b0], ev[b].Kmat, sizeof(double) * n * ev[b].ldn, hipMemcpyDeviceToHost, c->stream));
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (size_t b = b0; b < b1; b++) {
             const int n = c->h_n[slots[b]];
             if (!(st[b] >= 0 && Lout[b] && n > 0)) continue;
             const double *hl = (const double *)(c->h_bounce + off[b - b0]);
+            const size_t ld = ev[b].ldn;
             double *Lo = Lout[b];
             for (int i = 0; i < n; i++)
                 for (int j = 0; j < n; j++) Lo[(size_t)i * n + j] = (j <= i) ? hl[(size_t)i * ld + j] : 0.0;
@@ -1444,7 +1448,7 @@ int medgp_factor_batch(medgp_ctx *c, int nbatch, const int32_t *slots, const dou
         for (int b = 0; b < nbatch; b++) {
             const int n = c->h_n[slots[b]];
             if (st[b] >= 0 && zout[b] && n > 0)
-                HIPCHK(c, hipMemcpyAsync(zout[b], c->dev.z + (size_t)b * ld, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(zout[b], ev[b].z, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
