@@ -11,11 +11,15 @@
 #include <cstring>
 #include <functional>
 #include <iostream>
+#include <atomic>
+#include <thread>
 #include <vector>
+#include <unistd.h>
 
 #include "medgp_experiment.hpp"
 #include "medgp_optimizer.hpp"
 #include "medgp_workpool.hpp"
+#include "medgp_loader.hpp"
 using namespace medgp;
 typedef std::vector<double> vec;
 typedef std::function<bool(const vec &, double &, vec &)> objective_t;
@@ -276,7 +280,81 @@ static int test_pool() {
     return 0;
 }
 
+// The read-ahead loader of medgp_train (medgp_loader.hpp): every ticket of the list is delivered exactly once whatever the number of
+// readers, the capacity, the consumer's pace and the shape of the list (also lists shorter than the number of readers: its first
+// version lost a reader's exit there and the trainer never ended); blocking takes wait for a full wave; a shared counter file splits
+// one list between two loaders without loss or duplicate; a counter file that cannot be opened is reported.
+static int test_loader(const char *tmpdir) {
+    struct Item { size_t k; };
+    for (int nthreads : {1, 2, 4, 8})
+        for (size_t count : {(size_t)0, (size_t)1, (size_t)3, (size_t)64, (size_t)257})
+            for (size_t cap : {(size_t)1, (size_t)2, (size_t)16, (size_t)400})
+                for (int rep = 0; rep < 3; rep++) {
+                    medgp::Tickets tk;
+                    std::atomic<int> loads{0};
+                    medgp::ReadAhead<Item> ra(count, tk, cap, nthreads, [&](size_t k) { loads++; if ((k + rep) % 7 == 0) std::this_thread::yield(); return std::unique_ptr<Item>(new Item{k}); });
+                    std::vector<int> hit(count, 0);
+                    size_t got = 0;
+                    int spins = 0;
+                    while (true) {
+                        const bool block = (rep != 1);
+                        auto v = ra.take(rep == 2 ? 5 : 1000, block);
+                        for (auto &it : v) { if (it->k >= count) { printf("LOADER_FAIL ticket %zu beyond %zu\n", it->k, count); return 1; } hit[it->k]++; got++; }
+                        if (v.empty()) {
+                            if (ra.exhausted()) break;
+                            if (!block) { std::this_thread::yield(); if (++spins > 50000000) { printf("LOADER_FAIL never exhausted (threads %d count %zu cap %zu)\n", nthreads, count, cap); return 1; } }
+                        }
+                        if (rep == 0 && got == count / 2) ra.set_cap(std::max<size_t>(1, cap / 8));
+                    }
+                    for (size_t k = 0; k < count; k++) if (hit[k] != 1) { printf("LOADER_FAIL ticket %zu delivered %d times (threads %d count %zu cap %zu rep %d)\n", k, hit[k], nthreads, count, cap, rep); return 1; }
+                    if ((size_t)loads.load() != count || ra.taken() != (long long)count || ra.failed()) { printf("LOADER_FAIL loads %d taken %lld of %zu\n", loads.load(), ra.taken(), count); return 1; }
+                }
+    {   // a blocking take returns a FULL wave (min(want, cap)) or everything that is left
+        medgp::Tickets tk;
+        medgp::ReadAhead<Item> ra(100, tk, 32, 3, [&](size_t k) { return std::unique_ptr<Item>(new Item{k}); });
+        size_t got = 0;
+        bool first = true;
+        while (!ra.exhausted()) {
+            auto v = ra.take(48, true);
+            if (first && v.size() != 32) { printf("LOADER_FAIL first blocking wave %zu != 32\n", v.size()); return 1; }
+            first = false;
+            got += v.size();
+        }
+        if (got != 100) { printf("LOADER_FAIL blocking waves delivered %zu of 100\n", got); return 1; }
+    }
+    {   // two loaders on ONE counter file
+        const std::string q = std::string(tmpdir) + "/loader_queue.cnt";
+        unlink(q.c_str());
+        medgp::Tickets ta, tb;
+        ta.path = q; tb.path = q;
+        const size_t count = 500;
+        std::vector<std::atomic<int>> hit(count);
+        for (auto &h : hit) h.store(0);
+        auto consume = [&](medgp::Tickets &tk, int nthreads) {
+            medgp::ReadAhead<Item> ra(count, tk, 8, nthreads, [&](size_t k) { return std::unique_ptr<Item>(new Item{k}); });
+            while (!ra.exhausted()) for (auto &it : ra.take(4, true)) hit[it->k]++;
+            return !ra.failed();
+        };
+        bool oka = true, okb = true;
+        std::thread t1([&] { oka = consume(ta, 3); }), t2([&] { okb = consume(tb, 2); });
+        t1.join(); t2.join();
+        for (size_t k = 0; k < count; k++) if (hit[k].load() != 1) { printf("LOADER_FAIL shared counter: ticket %zu delivered %d times\n", k, hit[k].load()); return 1; }
+        if (!oka || !okb) { printf("LOADER_FAIL shared counter reported a failure\n"); return 1; }
+        unlink(q.c_str());
+    }
+    {   // a counter file that cannot be opened
+        medgp::Tickets tk;
+        tk.path = std::string(tmpdir) + "/no/such/dir/q.cnt";
+        medgp::ReadAhead<Item> ra(10, tk, 4, 2, [&](size_t k) { return std::unique_ptr<Item>(new Item{k}); });
+        while (!ra.exhausted()) ra.take(4, true);
+        if (!ra.failed() || ra.taken() != 0) { printf("LOADER_FAIL unreadable counter not reported\n"); return 1; }
+    }
+    printf("LOADER_OK\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 3 && !strcmp(argv[1], "loader")) return test_loader(argv[2]);
     if (argc >= 2 && !strcmp(argv[1], "scg")) return test_scg();
     if (argc >= 2 && !strcmp(argv[1], "pool")) return test_pool();
     if (argc >= 3 && !strcmp(argv[1], "optdump")) return opt_dump(argv[2]);

@@ -43,6 +43,7 @@
 #include "medgp_host.hpp"
 #include "medgp_optimizer.hpp"
 #include "medgp_workpool.hpp"
+#include "medgp_loader.hpp"
 
 using namespace medgp;
 using std::cout;
@@ -91,29 +92,6 @@ bool upload_priors(medgp_ctx *ctx, const vector<Patient *> &ps, int H, WorkPool 
     return medgp_set_priors(ctx, (int)n, slots.data(), flag.data(), type.data(), ex.data(), p0.data(), p1.data()) == 0;
 }
 
-// the shared work counter: atomic fetch-and-increment of the integer in `path` (the same file protocol as
-// medgp_amd/train_cohort.py take_ticket); without a path, a counter of this process
-struct Tickets {
-    string path;
-    std::atomic<long long> local{0};
-    long long take() {
-        if (path.empty()) return local.fetch_add(1);
-        const int fd = open(path.c_str(), O_RDWR | O_CREAT, 0644);
-        if (fd < 0) return -1;
-        long long k = -1;
-        if (flock(fd, LOCK_EX) == 0) {
-            char buf[40] = {0};
-            const ssize_t r = read(fd, buf, sizeof buf - 1);
-            k = (r > 0) ? atoll(buf) : 0;
-            const string s = std::to_string(k + 1);
-            if (lseek(fd, 0, SEEK_SET) != 0 || ftruncate(fd, 0) != 0 || write(fd, s.data(), s.size()) != (ssize_t)s.size()) k = -1;
-            flock(fd, LOCK_UN);
-        }
-        close(fd);
-        return k;
-    }
-};
-
 // observations of a patient from the headers of its feature files (first token = count, ref: dataio/c_experiment.cpp:296-299);
 // 0 when a file is missing (the real load then reports it)
 int header_count(const c_experiment &ex, const string &PAN) {
@@ -125,103 +103,6 @@ int header_count(const c_experiment &ex, const string &PAN) {
     }
     return n;
 }
-
-// Background reader: takes tickets, loads the patients they name (ref: dataio/c_experiment.cpp:254-309, D feature files each) and
-// keeps up to `cap` of them ready, so that an admission never waits for the file system while the device idles.  (Not more than an
-// eighth of the resident set: with a shared counter, patients held ready here are patients an idle trainer elsewhere cannot take.)
-class Loader {
-public:
-    Loader(const c_experiment &ex_, const vector<string> &pans_, const vector<int> &order_, Tickets &tk_, size_t cap_, int nthreads)
-        : ex(ex_), pans(pans_), order(order_), tk(tk_), cap(std::max<size_t>(cap_, 1)) {
-        const int n = std::max(1, nthreads);
-        live = n;                            // (before the first reader starts: a reader that finds the list exhausted decrements it)
-        for (int i = 0; i < n; i++) th.emplace_back([this] { run(); });
-    }
-    ~Loader() {
-        { std::lock_guard<std::mutex> l(mu); stop = true; }
-        cv_space.notify_all();
-        for (auto &t : th) t.join();
-    }
-    // up to `want` loaded patients; blocks only when `block` and nothing is ready while readers are still at work
-    vector<std::unique_ptr<Patient>> take(size_t want, bool block) {
-        vector<std::unique_ptr<Patient>> out;
-        std::unique_lock<std::mutex> l(mu);
-        // (blocking: a full wave -- the caller's device is idle, one large admission beats many small ones)
-        if (block) cv_ready.wait(l, [&] { return ready.size() >= std::min(want, cap) || live == 0; });
-        while (!ready.empty() && out.size() < want) { out.push_back(std::move(ready.front())); ready.pop_front(); }
-        l.unlock();
-        cv_space.notify_all();
-        return out;
-    }
-    void set_cap(size_t c) {   // (smaller: readers finish what they hold and then wait)
-        { std::lock_guard<std::mutex> l(mu); cap = std::max<size_t>(c, 1); }
-        cv_space.notify_all();
-    }
-    bool exhausted() {   // nothing ready and nothing will come
-        std::lock_guard<std::mutex> l(mu);
-        return ready.empty() && live == 0;
-    }
-    long long taken() const { return n_taken.load(); }
-    bool failed() const { return counter_failed.load(); }
-
-private:
-    void run() {
-        while (true) {
-            {
-                std::unique_lock<std::mutex> l(mu);
-                cv_space.wait(l, [&] { return stop || ready.size() + inflight < cap; });
-                if (stop) break;
-                inflight++;
-            }
-            const long long k = tk.take();
-            if (k < 0) counter_failed.store(true);   // the shared counter file could not be opened / locked / rewritten: the run must not end as a success
-            std::unique_ptr<Patient> p;
-            if (k >= 0 && k < (long long)order.size()) {
-                n_taken.fetch_add(1);
-                p.reset(new Patient());
-                p->index = order[(size_t)k];
-                p->PAN = pans[(size_t)p->index];
-                c_experiment e = ex;                 // own error string per reader
-                std::ostringstream os;
-                os << "running individual training..." << endl << "current patinet PAN = " << p->PAN << endl;
-                if (!e.get_one_patient_data(p->PAN, p->meta, p->t, p->y)) p->load_err = e.error();
-                else {
-                    os << "current number of data points = " << p->t.size() << endl;
-                    vector<int> count_array(e.get_feature_index().size(), 0);
-                    for (size_t i = 0; i < p->t.size(); i++) count_array[p->meta[i]] += 1;
-                    for (int c : count_array) if (c < 2) { p->sample_flag = false; break; }   // ref :185-197
-                    if (!p->sample_flag) os << "skip due to insufficient # of samples" << endl;
-                }
-                p->load_log = os.str();
-            }
-            std::unique_lock<std::mutex> l(mu);
-            inflight--;
-            const bool more = (bool)p;
-            if (more) ready.push_back(std::move(p));
-            else live--;                  // the list is exhausted (or the counter file failed)
-            l.unlock();
-            cv_ready.notify_all();
-            cv_space.notify_all();        // (a reader waiting for room must see that this one is no longer in flight)
-            if (!more) return;
-        }
-        std::lock_guard<std::mutex> l(mu);
-        live--;
-        cv_ready.notify_all();
-    }
-    const c_experiment &ex;
-    const vector<string> &pans;
-    const vector<int> &order;
-    Tickets &tk;
-    size_t cap, inflight = 0;
-    int live = 0;
-    bool stop = false;
-    std::atomic<long long> n_taken{0};
-    std::atomic<bool> counter_failed{false};
-    std::deque<std::unique_ptr<Patient>> ready;
-    std::mutex mu;
-    std::condition_variable cv_ready, cv_space;
-    vector<std::thread> th;
-};
 
 }  // namespace
 
@@ -318,7 +199,26 @@ static int train_main(int argc, const char *argv[]) {
     tickets.path = queue_file;
     // (read-ahead: the whole resident set while it is filled for the first time -- on all host threads, nothing else runs yet -- then an
     //  eighth of it, set below once every group has been submitted once)
-    Loader loader(curr_exp, pans, order, tickets, (size_t)resident, std::max(1, host_threads));
+    // one patient of the list, loaded (ref: dataio/c_experiment.cpp:254-309, D feature files each) and checked (ref :185-197)
+    auto load_patient = [&](size_t k) -> std::unique_ptr<Patient> {
+        std::unique_ptr<Patient> p(new Patient());
+        p->index = order[k];
+        p->PAN = pans[(size_t)p->index];
+        c_experiment e = curr_exp;                 // own error string per reader
+        std::ostringstream os;
+        os << "running individual training..." << endl << "current patinet PAN = " << p->PAN << endl;
+        if (!e.get_one_patient_data(p->PAN, p->meta, p->t, p->y)) p->load_err = e.error();
+        else {
+            os << "current number of data points = " << p->t.size() << endl;
+            vector<int> count_array(e.get_feature_index().size(), 0);
+            for (size_t i = 0; i < p->t.size(); i++) count_array[p->meta[i]] += 1;
+            for (int c : count_array) if (c < 2) { p->sample_flag = false; break; }
+            if (!p->sample_flag) os << "skip due to insufficient # of samples" << endl;
+        }
+        p->load_log = os.str();
+        return p;
+    };
+    ReadAhead<Patient> loader(order.size(), tickets, (size_t)resident, std::max(1, host_threads), load_patient);
     bool filled = false;
 
     vector<vector<double>> global_hyp_array;
