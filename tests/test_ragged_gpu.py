@@ -109,3 +109,60 @@ def test_get_factor_after_a_ragged_call(cohort):
         np.testing.assert_allclose(linv, ref["linv"], rtol=2e-6, atol=1e-6 * np.abs(ref["linv"]).max())
         assert abs(beta - ref["beta"]) <= 1e-6 * abs(ref["beta"])
         assert np.all(np.triu(linv, 1) == 0)
+
+
+def test_arenas_grow_with_the_calls_when_the_reservation_is_huge():
+    """medgp_reserve(max_batch x max_n^2 beyond 8 GB) allocates no per-entry matrices up front: 2048 x N = 20000 would be 13 TB.  The
+    calls grow the arenas to what their size classes need, results are the oracle's, and a later, larger call grows them again."""
+    Dm, Qm, Rm = 2, 2, 2
+    ns = [40, 700, 130, 9, 300]
+    pts = [synth.patient(5, p, Dm, n) for p, n in enumerate(ns)]
+    th = np.stack([synth.theta(5, p, 7, Qm, Dm, Rm) for p in range(len(ns))])
+    ctx = medgp_amd.Context(7, Qm, Dm, Rm)
+    ctx.reserve(8, 20000, 2048)
+    ctx.set_patients(np.arange(len(ns)), pts)
+    for sel in ([0, 3], [0, 1, 2, 3, 4], [1] * 40 + [2, 4]):          # growing needs: 2 small entries, all five, 40 x N = 700
+        sel = np.array(sel)
+        nlml, grad, st = ctx.nlml_grad(sel, th[sel], True)
+        assert np.all(st == 0)
+        for b in (0, len(sel) - 1):
+            p = sel[b]
+            ref = O.nlml_grad(7, Qm, Dm, Rm, *pts[p], th[p])
+            _check(int(p), nlml[b], grad[b], ref["nlml"], ref["grad"])
+    ctx.close()
+
+
+def test_route_rule_of_uniform_calls_is_the_round_4_rule(monkeypatch):
+    """For a uniform call the per-class rule on the cost model reduces to the measured thresholds of round 4 (profiles/r04_route_table.txt):
+    look-ahead schedule up to 7/16 #CU entries (112) of three or four blocks and up to 9/16 #CU (144) from five blocks on, never for two;
+    one workgroup per entry beyond -- 4-wave shape when there are more entries than CUs or at most four blocks, else 8 waves."""
+    Dm, Qm, Rm = 1, 1, 0
+    ctx = medgp_amd.Context(8, Qm, Dm, Rm)
+    ctx.reserve(4, 330, 300)
+    for s, n in enumerate((100, 200, 330)):
+        ctx.set_patient(s, None, *synth.patient(3, s, 1, n)[1:])
+    th = synth.theta(3, 0, 8, Qm, 1, 0)
+    for slot, blocks, cases in ((0, 2, [(8, 0), (200, 0)]), (1, 4, [(112, 2), (113, 0), (300, 0)]), (2, 6, [(144, 2), (145, 1), (257, 0)])):
+        for count, route in cases:
+            ctx.nlml_grad(np.full(count, slot), np.tile(th, (count, 1)), False)
+            assert ctx.last_plan() == [(count, blocks, route)], (blocks, count, ctx.last_plan())
+    ctx.close()
+
+
+def test_one_class_switch_gives_the_same_values(cohort, monkeypatch):
+    """MEDGP_NO_CLASSES=1 (the A/B switch of bench.py's `before` leg: one class, one route per call as in rounds 1-4) must still be a
+    correct evaluator: same statuses, values within the parity tolerance of the default plan's."""
+    ctx, pts, th, ns = cohort
+    sel = np.argsort(ns, kind="stable")[100:220]
+    nlml, grad, st = ctx.nlml_grad(sel, th[sel], True)
+    monkeypatch.setenv("MEDGP_NO_CLASSES", "1")
+    ctx2 = medgp_amd.Context(7, Q, D, R)
+    ctx2.reserve(len(sel), int(ns[sel].max()), len(sel))
+    ctx2.set_patients(np.arange(len(sel)), [pts[p] for p in sel])
+    ctx2.set_prior(-1, *synth.hier_gamma_prior(Q, D, R, 0.01))
+    nlml2, grad2, st2 = ctx2.nlml_grad(np.arange(len(sel)), th[sel], True)
+    assert len(ctx2.last_plan()) == 1 and np.array_equal(st, st2)
+    np.testing.assert_allclose(nlml2, nlml, rtol=1e-12)
+    gs = np.abs(grad).max(axis=1, keepdims=True)
+    assert (np.abs(grad2 - grad) / np.maximum(np.abs(grad), 1e-3 * gs)).max() <= 1e-8
+    ctx2.close()

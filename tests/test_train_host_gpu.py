@@ -216,6 +216,13 @@ def test_train_continuous_admission_matches_single_runs(tmp_path, built_lib, pri
         fin = re.findall(r"^finish individual id: (\S+) w/", out, flags=re.M)
         assert fin == pans, (tag, fin)
     assert int(open(tmp_path / "q.cnt").read()) >= 11          # the shared counter was walked to the end
+    # a work counter that cannot be opened must not end as a success with nothing trained
+    ex = make_experiment(tmp_path / "bad", pans[:3], D=2, Q=3, R=2, N=Ns[:3], prior_index=prior_index, opt=opt)
+    plist = tmp_path / "pans_bad.txt"
+    plist.write_text("\n".join(pans[:3]) + "\n")
+    r = subprocess.run([EXE, "--cfg", ex["cfg"], "--pan-list", str(plist), "--queue", str(tmp_path / "no" / "such" / "dir" / "q.cnt")],
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode != 0 and "work counter" in r.stdout
 
 
 @pytest.mark.parametrize("kernel_index", [0, 8])
