@@ -194,6 +194,7 @@ static int train_main(int argc, const char *argv[]) {
     if (pin_route && medgp_pin_route(ctx, 1)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
     vector<int> free_slots;
     for (int s = resident - 1; s >= 0; s--) free_slots.push_back(s);
+    vector<uint8_t> slot_used((size_t)resident, 0);   // slots that have held a patient (and may hold its prior on the device)
 
     Tickets tickets;
     tickets.path = queue_file;
@@ -289,8 +290,12 @@ static int train_main(int argc, const char *argv[]) {
                 cout << "ERROR: " << medgp_last_error(ctx) << endl; return false;
             }
         }
-        vector<Patient *> unprior;   // (a slot may still carry its previous patient's prior: the screening runs without one, ref :222-226)
-        for (Patient *p : live) { p->prior.initialize_param(curr_exp.get_cov_num(), curr_exp.get_mean_num(), curr_exp.get_lik_num()); unprior.push_back(p); }
+        vector<Patient *> unprior;   // (a RE-USED slot still carries its previous patient's prior: the screening runs without one, ref :222-226)
+        for (Patient *p : live) {
+            p->prior.initialize_param(curr_exp.get_cov_num(), curr_exp.get_mean_num(), curr_exp.get_lik_num());
+            if (slot_used[(size_t)p->slot]) unprior.push_back(p);
+            slot_used[(size_t)p->slot] = 1;
+        }
         if (!upload_priors(ctx, unprior, H, pool)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return false; }
         if (admissions == 1) cout << "finish initialization of prior" << endl;
         {
