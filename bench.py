@@ -379,6 +379,31 @@ def host_paths(out, dev_index, seed):
             "gradient_evals_per_s_outside_admissions": float(m4.group(1)) if m4 else None,
             "gradient_evals_per_s_whole_loop": float(m4.group(2)) if m4 else None,
             "output_files": len([f for f in os.listdir(ex2["dirs"]["train"]) if f.startswith("train_")])}
+        # ---- the same trainer on a HEAVY-TAILED cohort at the real budget: 512 patients, log-normal sizes (median 263, max 5832): every
+        #      lock-step batch and every screening chunk is a ragged call scheduled by size classes (round 5)
+        P3 = 512
+        ns3 = [max(48, int(v)) for v in synth.ragged_sizes(0, P3)]
+        pans3 = [f"R{k:05d}" for k in range(P3)]
+        ex3 = make_experiment(os.path.join(tmp, "ragged"), pans3, D=D, Q=Q, R=R, N=ns3, feature_index=tuple(range(D)), seed=seed + 6,
+                              opt=dict(random_init_num=1000, top_iteration_num=40, iteration_num_per_update=30))
+        plist3 = os.path.join(tmp, "ragged_pans.txt")
+        open(plist3, "w").write("\n".join(pans3) + "\n")
+        t0 = time.perf_counter()
+        r = subprocess.run([os.path.join(host, "medgp_train"), "--cfg", ex3["cfg"], "--pan-list", plist3, "--resident", "512", "--device", str(dev_index)],
+                           capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError("medgp_train (ragged, real budget) rc %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:]))
+        m1 = re.search(r"optimization finished: (\d+) nlml\+grad evaluations in (\d+) lock-step batches", r.stdout)
+        m3 = re.search(r"continuous admission: (\d+) patients through (\d+) resident slots in (\d+) admissions \(([0-9.e+-]+) s, of which screening ([0-9.e+-]+) s for (\d+) nlml-only", r.stdout)
+        m4 = re.search(r"outside admissions: ([0-9.e+-]+); of the whole loop: ([0-9.e+-]+)", r.stdout)
+        out["train_cohort_512_lognormal_D24_real_budget"] = {
+            "patients": P3, "n_median": int(np.median(ns3)), "n_max": int(max(ns3)), "D": D, "random_init_num": 1000, "top_iteration_num": 40,
+            "iteration_num_per_update": 30, "process_wall_s": wall, "gradient_evaluations": int(m1.group(1)) if m1 else None,
+            "lockstep_batches": int(m1.group(2)) if m1 else None, "screening_s": float(m3.group(5)) if m3 else None,
+            "screening_evaluations": int(m3.group(6)) if m3 else None,
+            "gradient_evals_per_s_outside_admissions": float(m4.group(1)) if m4 else None,
+            "trained": sum(open(os.path.join(ex3["dirs"]["train"], f"train_flag_{p}.txt")).read().strip() == "1" for p in pans3)}
         # ---- f3: 64 test patients, D = 4, N 120 .. 200, both passes (with / without the online hyper updates)
         P, D, Q, R = 64, 4, 3, 2
         pans = [f"C{k:03d}" for k in range(P)]
