@@ -108,7 +108,7 @@ int header_count(const c_experiment &ex, const string &PAN) {
 
 static int train_main(int argc, const char *argv[]) {
     string exp_cfg, pan_arg, pan_list, queue_file, order_arg = "size";
-    int thread_num = 1, device = 0, max_batch = 1024, host_threads = 0, pingpong_min = 512, resident = 1024, admit_min = -1, max_n_arg = 0;
+    int thread_num = 1, device = 0, max_batch = 1024, host_threads = 0, pingpong_min = 512, merge_below = 256, resident = 1024, admit_min = -1, max_n_arg = 0;
     bool pin_route = false;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--cfg") && i + 1 < argc) exp_cfg = argv[++i];
@@ -119,6 +119,7 @@ static int train_main(int argc, const char *argv[]) {
         else if (!strcmp(argv[i], "--max-batch") && i + 1 < argc) max_batch = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--host-threads") && i + 1 < argc) host_threads = atoi(argv[++i]);   // 0 = usable cores (<= 8)
         else if (!strcmp(argv[i], "--pingpong-min") && i + 1 < argc) pingpong_min = atoi(argv[++i]);   // resident patients from which the lock-step loop runs them as two alternating halves
+        else if (!strcmp(argv[i], "--merge-below") && i + 1 < argc) merge_below = atoi(argv[++i]);   // active patients below which the alternating groups are merged into one (tail of the list)
         else if (!strcmp(argv[i], "--resident") && i + 1 < argc) resident = atoi(argv[++i]);           // patients kept on the device at once (continuous admission)
         else if (!strcmp(argv[i], "--admit-min") && i + 1 < argc) admit_min = atoi(argv[++i]);         // free places of a group from which new patients are admitted (default: an eighth of the group)
         else if (!strcmp(argv[i], "--queue") && i + 1 < argc) queue_file = argv[++i];                  // shared work counter: several trainers walk ONE list
@@ -433,8 +434,10 @@ static int train_main(int argc, const char *argv[]) {
         std::deque<int> ready;
         for (int g = 0; g < (int)groups.size(); g++) ready.push_back(g);
         int free_lanes[2] = {1, 1};
-        // Re-forming at the tail: once the list is exhausted patients only leave, and when what is left no longer fills the chip as ONE
-        // launch (fewer than --pingpong-min patients altogether), two quarter-full launches per step are slower than one.  When that point
+        // Re-forming at the tail: once the list is exhausted patients only leave, and when what is left no longer fills HALF the chip as
+        // one launch (fewer than --merge-below = 256 patients altogether: two groups of < 128), two small launches per step are slower than
+        // one.  (Down to there two groups of 255 cost the device what one group of 510 costs -- one workgroup per CU in the 8-wave shape
+        // against two in the 4-wave shape -- and keep the host's share of a step hidden behind the other group's evaluation.)  When that point
         // is reached nothing new is queued until the device is idle, then the groups are merged.  (Merging earlier -- round 4 merged at
         // twice that size -- gives up the overlap of one group's state machines with the other group's evaluation for the whole tail:
         // 2048 patients through 1024 slots spent half of the run in one merged group of 979.)
@@ -442,7 +445,7 @@ static int train_main(int argc, const char *argv[]) {
             if (!loader.exhausted()) return false;
             size_t act = 0, nonempty = 0;
             for (const Group &g : groups) { act += g.mem.size(); nonempty += g.mem.empty() ? 0 : 1; }
-            return nonempty >= 2 && act <= bufcap && (int)act <= max_batch && (int)act < std::max(1, pingpong_min);
+            return nonempty >= 2 && act <= bufcap && (int)act <= max_batch && (int)act < std::max(1, std::min(merge_below, pingpong_min));
         };
         while (!ready.empty() || !inflight.empty()) {
             if (inflight.empty() && groups.size() > 1 && want_merge()) {
