@@ -69,26 +69,14 @@ __global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, i
         tix = rest % ntiles;
     } else {
         int x = blockIdx.x;
-        // (fewer than 8 entries: ids in groups of 8 per entry, see below -- the id space is nbatch x ntiles rounded up to 8)
-        const int total = nbatch * (nbatch < 8 ? ((ntiles + 7) & ~7) : ntiles);
+        const int total = nbatch * ntiles;
         if (x >= total) return;
         if (PF > 1 && total <= 1024 && ((x >> 8) & 1)) {   // odd group of 256: reversed
             const int v0 = x & ~255, m = min(256, total - v0);
             x = v0 + (m - 1 - (x & 255));
         }
-        if (nbatch < 8) {
-            // (round 5) fewer entries than XCDs -- the few-large-patients classes of a ragged call, 4 entries of 35 .. 57 blocks: with the
-            // entry index fastest, entry b's tiles all have ids = b (mod nbatch), i.e. land on 8 / nbatch of the 8 XCDs, and the largest
-            // entry's tiles -- most of the launch's work -- queue on 64 CUs.  Groups of 8 consecutive ids (= one tile per XCD) now belong to
-            // one entry, the entries take turns group by group.  Launch order only: same tiles, same bits.
-            const int g8 = x >> 3;
-            b = g8 % nbatch;
-            tix = (g8 / nbatch) * 8 + (x & 7);
-            if (tix >= ntiles) return;
-        } else {
-            b = x % nbatch;
-            tix = x / nbatch;
-        }
+        b = x % nbatch;
+        tix = x / nbatch;
     }
     if (b >= nbatch) return;
     if (L.status[b] < 0) return;

@@ -43,7 +43,7 @@ struct SizeClass {
     int ld = 64;               // leading dimension of the class view
     size_t off_mat = 0, off_vec = 0, off_tab = 0, off_slab = 0;   // offsets (doubles) of the class inside Kmat/Linv, z/alpha/wdiag, cs/sn, slab
     long long tsum = 0;        // sum of the cost model over its entries (route rule)
-    int route = ROUTE_WG84;    // last route taken (diagnostics: medgp_last_plan)
+    int route = ROUTE_WG84;    // last route taken (diagnostics: medgp_debug_plan)
 };
 struct BatchPlan {
     bool identity = true;      // internal order == caller order
@@ -557,8 +557,7 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
 #endif
     if (flag_grad) {
         const int wg_tiles = tri(nt64);
-        // (fewer than 8 entries: the kernel deals ids in groups of 8 per entry, nbatch x wg_tiles rounded up to 8 of them)
-        const dim3 tg(nbatch < 8 ? nbatch * ((wg_tiles + 7) & ~7) : 8 * ((nbatch + 7) / 8) * wg_tiles), tb(WG_THREADS);
+        const dim3 tg(8 * ((nbatch + 7) / 8) * wg_tiles), tb(WG_THREADS);
         from_slab = 1;
         Launcher lw(c, KID_WGRAD, stream);
         // few large patients (the launch fills the chip less than four times): operand prefetch two chunks ahead + serpentine tile order (kernels_wgrad.h)
