@@ -43,7 +43,7 @@ struct SizeClass {
     int ld = 64;               // leading dimension of the class view
     size_t off_mat = 0, off_vec = 0, off_tab = 0, off_slab = 0;   // offsets (doubles) of the class inside Kmat/Linv, z/alpha/wdiag, cs/sn, slab
     long long tsum = 0;        // sum of the cost model over its entries (route rule)
-    int route = ROUTE_WG84;    // last route taken (diagnostics: medgp_debug_plan)
+    int route = ROUTE_WG84;    // last route taken (diagnostics: medgp_last_plan)
 };
 struct BatchPlan {
     bool identity = true;      // internal order == caller order
