@@ -87,6 +87,11 @@ struct LaArgs {
     int maxslice;         // slices per row block the scratch is dimensioned for
     int rows;             // row blocks the scratch is dimensioned for (2 nbmax + 1)
     int ring;             // index mask of the chain's hand-off slabs xk2 / pnx / dterm / dsum: 1 = by step parity
+    int nbatch;           // entries of the class.  The grids' x extent is nbatch, or nbatch | 1 for a class whose entries differ in size:
+                          // workgroup ids (y * extent + x) go round-robin over the 8 XCDs, so with an extent of 2, 4, 8, ... every entry's
+                          // tasks land on half, a quarter, an eighth of the chip -- balanced when the entries are equally large, but in a
+                          // ragged class the largest entry's tasks queue there (round 5: N = 3595 + 3 x 2400 k_la_step 3.73 ms, + 4 x 2400
+                          // 2.74 ms).  An odd extent puts every entry on all XCDs; the workgroups of the padding column exit.
 };
 
 // row block index inside the scratch: M_i -> i, U_rho -> nbmax + rho, Y -> 2 nbmax
@@ -231,6 +236,7 @@ __device__ __forceinline__ void la_x_to_lds(double (*Xs)[LA_S], const v2d (&xreg
 __global__ void __launch_bounds__(LA_THREADS) k_la_prologue(MedgpDev L, LaArgs A, int want_mode) {
     __shared__ LaSmem sm;
     const int b = blockIdx.x;
+    if (b >= A.nbatch) return;   // (padding column of a ragged class)
     // status, size (k_prep's copy) and slot are requested together: `status -> branch -> slot -> size of the slot` was a chain of three
     // scalar-memory round trips in front of the first factorisation
     const int st0 = L.status[b], n0 = L.bn[b], slot = L.bslot[b];
@@ -832,6 +838,7 @@ __device__ __forceinline__ int la_body(const MedgpDev &L, const LaArgs &A, LaSme
 __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A, int k, int want_mode, int nLrowsL, int park) {
     __shared__ LaSmem sm;
     const int b = blockIdx.x;
+    if (b >= A.nbatch) return;   // (padding column of a ragged class)
     if (park >= 0 && (int)blockIdx.y == park) {
         const int st0 = L.status[b], n0 = L.bn[b];
         const int nb = medgp_roundup(__builtin_amdgcn_readfirstlane(n0), 64) / 64;
@@ -858,6 +865,7 @@ __global__ void __launch_bounds__(LA_THREADS, 2) k_la_step(MedgpDev L, LaArgs A,
 __global__ void __launch_bounds__(256) k_la_finish(MedgpDev L, LaArgs A, int want_mode) {
     __shared__ double red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (b >= A.nbatch) return;   // (padding column of a ragged class)
     const int st0 = L.status[b], n0 = L.bn[b];
     if (st0 < 0) return;
     const int n = n0, ld = L.ldn, npad = medgp_roundup(n, 64), nb = npad / 64;

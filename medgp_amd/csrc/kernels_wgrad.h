@@ -45,8 +45,13 @@
 // launch of at most 1024 workgroups (all resident at once, so placement is static: workgroups x, x + 256, x + 512 share a CU -- traced) also
 // deals its tiles in serpentine order, so that the CU holding the longest k range gets the shortest one next.  Scheduling only: same MFMA
 // sequence per tile, same bits.
+// nbp (launches of fewer than 64 entries): stride of the entry index in the workgroup id, nbatch or nbatch | 1.  Workgroup ids go round-robin
+// over the 8 XCDs, so with the entry index fastest entry b's tiles land on 8 / gcd(stride, 8) ... of them: harmless when all entries are
+// equally large (every XCD gets the same work: 4 x N = 2048 0.062 ms per entry, 5 x 0.062), but in a RAGGED class of 2, 4 or 8 entries
+// the largest entry's tiles -- most of the work -- queue on half, a quarter, an eighth of the chip (round 5, scratch/wgrad_ragged.py:
+// N = 3595 + 3 x 2400: 1.18 ms, + 4 x 2400: 0.73 ms).  An odd stride puts every entry on all XCDs; the ids of the padding entry exit.
 template <int QT, int Q0 = 0, int PF = 1>
-__global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, int nbatch, int ntiles) {
+__global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, int nbatch, int ntiles, int nbp) {
     // staging buffers (phase 1) and the W tile (phase 2/3) share storage
     __shared__ __attribute__((aligned(16))) double smem[2 * 64 * (WG_KC + 2)];
     typedef double (*BsT)[64][WG_KC + 2];
@@ -69,14 +74,14 @@ __global__ void __launch_bounds__(WG_THREADS, WG_MINWAVES) k_wgrad(MedgpDev L, i
         tix = rest % ntiles;
     } else {
         int x = blockIdx.x;
-        const int total = nbatch * ntiles;
+        const int total = nbp * ntiles;
         if (x >= total) return;
         if (PF > 1 && total <= 1024 && ((x >> 8) & 1)) {   // odd group of 256: reversed
             const int v0 = x & ~255, m = min(256, total - v0);
             x = v0 + (m - 1 - (x & 255));
         }
-        b = x % nbatch;
-        tix = x / nbatch;
+        b = x % nbp;
+        tix = x / nbp;
     }
     if (b >= nbatch) return;
     if (L.status[b] < 0) return;

@@ -457,6 +457,7 @@ int ensure_la(medgp_ctx *c, std::vector<LaNeed> &v) {
         A.maxslice = (e.nbmax + LA_SLICE - 1) / LA_SLICE;
         A.rows = 2 * e.nbmax + 1;
         A.ring = 1;
+        A.nbatch = e.count;
         A.part = pp;
         A.ybuf = ps;
         A.xk2 = ps + nb * 64 * e.ld;
@@ -477,6 +478,8 @@ int ensure_la(medgp_ctx *c, std::vector<LaNeed> &v) {
 int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nbatch, int nt64, const double *theta_dev,
                      int flag_grad, bool need_inverse, int min_n, double *nlml_dev, double *grad_dev, int32_t *status_dev,
                      bool store_ukk, const int *entry_n, int route, const LaArgs *la_in) {
+    bool ragged = false;   // entries of different 64-block counts in this class
+    for (int bb = 1; bb < nbatch; bb++) ragged = ragged || blocks64(entry_n[bb]) != blocks64(entry_n[0]);
     { Launcher l(c, KID_PREP, stream); hipLaunchKernelGGL(k_prep, dim3(nbatch, 1 + (L.Q * L.ldn + PREP_CHUNK - 1) / PREP_CHUNK + ((theta_dev && L.kidx == 7) ? (L.Q * L.D * L.D + PREP_BCHUNK - 1) / PREP_BCHUNK : 0)), dim3(256), 0, stream, L, theta_dev, min_n); }
     auto launch_assemble = [&]() {
         Launcher l(c, KID_ASSEMBLE, stream);
@@ -511,7 +514,8 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
             launch_assemble();
             // entries of a single 64-block: one workgroup each (the same kernel, hence the same bits, as in any other call)
             if (any_small) { Launcher l(c, KID_CHOLINV, stream); hipLaunchKernelGGL((k_cholinv<8, 4, 1>), dim3(nbatch), dim3(512), 0, stream, L, want_mode); }
-            { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_prologue, dim3(nbatch, 1 + nt64), dim3(LA_THREADS), 0, stream, L, la, want_mode); }
+            const int nbx = ragged ? (nbatch | 1) : nbatch;   // x extent of the look-ahead grids: odd for a ragged class (LaArgs::nbatch)
+            { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_prologue, dim3(nbx, 1 + nt64), dim3(LA_THREADS), 0, stream, L, la, want_mode); }
             auto step_counts = [&](int k, int *nF, int *nLrows, int *nsl) {
                 const int nMF = std::max(nt64 - (k + 2), 0), nUF = (want_mode & 1) ? k + 1 : 0, nUL = (want_mode & 1) ? k : 0;
                 *nF = nMF + nUF + 1;
@@ -526,12 +530,12 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
                 const int ntask = 1 + LA_NAUX(k) + nF + nLrows * nsl;   // D, the F row blocks, R and / or H, the look-ahead slices
                 // (workgroup ids are y * nbatch + x: with nbatch entries the chains are ids 0 .. nbatch-1 and their first neighbours
                 //  ids 256 .. 256+nbatch-1, i.e. task y = 256 / nbatch of every entry)
-                const int pk = (c->la_park > 0 && nbatch <= c->la_park_maxbatch && c->la_park % nbatch == 0) ? c->la_park / nbatch : -1;
+                const int pk = (c->la_park > 0 && nbx == nbatch && nbatch <= c->la_park_maxbatch && c->la_park % nbatch == 0) ? c->la_park / nbatch : -1;
                 const int park = (pk > 0 && ntask > pk && k + 1 < nt64) ? pk : -1;
                 Launcher l(c, KID_LA_STEP, stream);
-                hipLaunchKernelGGL(k_la_step, dim3(nbatch, ntask + (park >= 0 ? 1 : 0)), dim3(LA_THREADS), 0, stream, L, la, k, want_mode, nLrows, park);
+                hipLaunchKernelGGL(k_la_step, dim3(nbx, ntask + (park >= 0 ? 1 : 0)), dim3(LA_THREADS), 0, stream, L, la, k, want_mode, nLrows, park);
             }
-            { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_finish, dim3(nbatch, 4 * nt64), dim3(256), 0, stream, L, la, want_mode); }
+            { Launcher l(c, KID_LA_AUX, stream); hipLaunchKernelGGL(k_la_finish, dim3(nbx, 4 * nt64), dim3(256), 0, stream, L, la, want_mode); }
             // The reference's retry loop (c_inference_exact.cpp:99-111: add the noise vector again, at most 10 times), device
             // driven: entries whose one attempt above failed (status -2) are re-assembled and factored by k_cholinv's in-kernel
             // loop; for healthy entries this launch is one workgroup that reads a status word.  No host read-back, no wait.
@@ -557,13 +561,16 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
 #endif
     if (flag_grad) {
         const int wg_tiles = tri(nt64);
-        const dim3 tg(8 * ((nbatch + 7) / 8) * wg_tiles), tb(WG_THREADS);
+        // entries of different sizes in a launch of few entries: odd stride of the entry index, so that every entry's tiles go to all
+        // XCDs (kernels_wgrad.h); equally large entries keep the stride nbatch (balanced as it is, and the measured form)
+        const int nbp = (ragged && nbatch < 64) ? (nbatch | 1) : nbatch;
+        const dim3 tg(std::max(8 * ((nbatch + 7) / 8), nbp) * wg_tiles), tb(WG_THREADS);
         from_slab = 1;
         Launcher lw(c, KID_WGRAD, stream);
         // few large patients (the launch fills the chip less than four times): operand prefetch two chunks ahead + serpentine tile order (kernels_wgrad.h)
         const int pf = c->wgrad_deep >= 0 ? c->wgrad_deep : ((long)nbatch * wg_tiles <= 16L * c->num_cu ? 2 : 1);
-#define MEDGP_WGL(QQ, Q0) do { if (pf >= 2) hipLaunchKernelGGL((k_wgrad<QQ, Q0, 2>), tg, tb, 0, stream, L, nbatch, wg_tiles); \
-                               else hipLaunchKernelGGL((k_wgrad<QQ, Q0, 1>), tg, tb, 0, stream, L, nbatch, wg_tiles); } while (0)
+#define MEDGP_WGL(QQ, Q0) do { if (pf >= 2) hipLaunchKernelGGL((k_wgrad<QQ, Q0, 2>), tg, tb, 0, stream, L, nbatch, wg_tiles, nbp); \
+                               else hipLaunchKernelGGL((k_wgrad<QQ, Q0, 1>), tg, tb, 0, stream, L, nbatch, wg_tiles, nbp); } while (0)
 #define MEDGP_WG1(QQ) case QQ: MEDGP_WGL(QQ, 0); break;
         // 9 .. 16 components: two launches, each reducing its own components into its own slab planes (kernels_wgrad.h)
 #define MEDGP_WG2(QR) case 8 + QR: MEDGP_WGL(8, 0); MEDGP_WGL(QR, 8); break;
