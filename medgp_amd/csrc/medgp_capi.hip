@@ -1185,6 +1185,14 @@ int medgp_screen(medgp_ctx *c, int nslots, const int32_t *slots, int ninit, cons
     }
     double *hn = (double *)c->h_bounce;
     int32_t *hs = (int32_t *)(c->h_bounce + sizeof(double) * total);
+    // The patients are walked LARGEST FIRST whatever the caller's order (results go back to the caller's rows at the end): a chunk that
+    // holds the last vectors of one patient and the first of the next then holds two patients of similar size -- one size class, one
+    // launch set -- where the caller's order (the trainer's read-ahead delivers patients as its readers finish) would put a handful of
+    // entries of a very different size into a class and a kernel chain of their own: measured on the 512-patient heavy-tailed cohort,
+    // 1000 vectors each: 8.7-11.3 s in arrival order against 5.0 s sorted.
+    std::vector<int> perm(nslots);
+    for (int s = 0; s < nslots; s++) perm[s] = s;
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return c->h_n[slots[a]] > c->h_n[slots[b]]; });
     // chunks of consecutive (patient, init) entries: at most max_batch of them, and at most 48 GB of per-entry matrices
     std::vector<int32_t> cs;
     std::vector<int> tp;
@@ -1196,7 +1204,7 @@ int medgp_screen(medgp_ctx *c, int nslots, const int32_t *slots, int ninit, cons
         long long bytes = 0;
         size_t e = e0;
         while (e < total && (int)cs.size() < c->max_batch) {
-            const int s = (int)(e / ninit), n = c->h_n[slots[s]];
+            const int s = perm[e / ninit], n = c->h_n[slots[s]];
             const long long ld = (std::max(n, 1) + 63) / 64 * 64, per = 16 * ld * ld;
             if (!cs.empty() && bytes + per > (48LL << 30)) break;
             cs.push_back(slots[s]); tp.push_back((int)(e % ninit));
@@ -1223,8 +1231,10 @@ int medgp_screen(medgp_ctx *c, int nslots, const int32_t *slots, int ninit, cons
     c->last_nbatch = 0;   // (the cached plan carries this call's theta rows: the next call lays its own out)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (rc) return rc;
-    std::memcpy(nlml, hn, sizeof(double) * total);
-    if (status) std::memcpy(status, hs, sizeof(int32_t) * total);
+    for (int sp = 0; sp < nslots; sp++) {   // walk order -> the caller's rows
+        std::memcpy(nlml + (size_t)perm[sp] * ninit, hn + (size_t)sp * ninit, sizeof(double) * ninit);
+        if (status) std::memcpy(status + (size_t)perm[sp] * ninit, hs + (size_t)sp * ninit, sizeof(int32_t) * ninit);
+    }
     return MEDGP_OK;
 }
 
