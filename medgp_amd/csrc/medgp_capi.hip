@@ -1207,6 +1207,10 @@ int medgp_screen(medgp_ctx *c, int nslots, const int32_t *slots, int ninit, cons
             const int s = perm[e / ninit], n = c->h_n[slots[s]];
             const long long ld = (std::max(n, 1) + 63) / 64 * 64, per = 16 * ld * ld;
             if (!cs.empty() && bytes + per > (48LL << 30)) break;
+            // Entries so large that 48 GB hold at most 144 of them take the look-ahead schedule anyway, whose throughput saturates at a
+            // few dozen entries: 32 per chunk then (N = 5832: 26 GB of matrices + scratch instead of 72 GB -- the FIRST use of device
+            // memory costs 0.1-0.2 s per GB on this platform: rocprofv3 --hip-trace of a 512-patient heavy-tailed run: hipMalloc 5.7 s)
+            if ((48LL << 30) / per <= 144 && (int)cs.size() >= 32) break;
             cs.push_back(slots[s]); tp.push_back((int)(e % ninit));
             bytes += per; e++;
         }

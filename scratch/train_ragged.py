@@ -16,7 +16,7 @@ NINIT = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 TOP = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 RES = sys.argv[4] if len(sys.argv) > 4 else "256"
 ns = [max(48, int(n)) for n in synth.ragged_sizes(0, P)]          # (at least two observations per output at D = 24)
-host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "medgp_amd", "host")
+host = os.environ.get("MEDGP_HOST_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "medgp_amd", "host")
 tmp = tempfile.mkdtemp(prefix="medgp_ragged_")
 pans = [f"P{k:05d}" for k in range(P)]
 ex = make_experiment(os.path.join(tmp, "train"), pans, D=24, Q=5, R=8, N=ns, feature_index=tuple(range(24)), seed=78,
