@@ -166,3 +166,27 @@ def test_one_class_switch_gives_the_same_values(cohort, monkeypatch):
     gs = np.abs(grad).max(axis=1, keepdims=True)
     assert (np.abs(grad2 - grad) / np.maximum(np.abs(grad), 1e-3 * gs)).max() <= 1e-8
     ctx2.close()
+
+
+@pytest.mark.parametrize("ns", [[900, 800, 700, 600], [1000, 960, 900, 840, 800, 760, 700, 590], [2000, 1100]])
+def test_ragged_classes_of_two_four_and_eight_entries(ns):
+    """Classes whose entries differ in block count take an odd stride of the entry index in k_wgrad's workgroup ids and an odd x extent
+    of the look-ahead grids (count | 1), so that every entry's workgroups go to all 8 XCDs instead of 8 / count of them; the padding
+    column's workgroups must do nothing.  One size class of 4 / 8 / 2 entries of different sizes on default routing (look-ahead
+    schedule), nlml + gradient and nlml-only, against the oracle."""
+    Dm, Qm, Rm = 4, 3, 2
+    pts = [synth.patient(23, p, Dm, n) for p, n in enumerate(ns)]
+    th = np.stack([synth.theta(23, p, 7, Qm, Dm, Rm) for p in range(len(ns))])
+    ctx = medgp_amd.Context(7, Qm, Dm, Rm)
+    ctx.reserve(len(ns), max(ns), len(ns))
+    ctx.set_patients(np.arange(len(ns)), pts)
+    nlml, grad, st = ctx.nlml_grad(np.arange(len(ns)), th, True)
+    plan = ctx.last_plan()
+    assert any(cnt == len(ns) and r == 2 for cnt, _, r in plan) or len(ns) == 2, plan
+    nlml0, _, st0 = ctx.nlml_grad(np.arange(len(ns)), th, False)
+    assert np.all(st == 0) and np.all(st0 == 0)
+    for p in range(len(ns)):
+        ref = O.nlml_grad(7, Qm, Dm, Rm, *pts[p], th[p], nthreads=4)
+        _check(p, nlml[p], grad[p], ref["nlml"], ref["grad"])
+        assert abs(nlml0[p] - ref["nlml"]) <= NLML_RTOL * abs(ref["nlml"])
+    ctx.close()
