@@ -51,6 +51,24 @@ def alg_work(kernel, N, Q, D, H):
     return table.get(kernel, (0.0, 0.0, "hbm"))
 
 
+def leg_roofline(kernel_ms, N, Q, D, H, P, nlml_only=False):
+    """Roofline fraction of the DOMINANT kernel of an auxiliary leg (verdict r5 item 6): its algorithmic flops (alg_work x the P
+    entries of the call; nlml only: no inverse, N^3/3 + 2 N^2 per entry) / its HIP-event time per call / fp64 peak.  For the
+    look-ahead schedule the time is the sum over the N / 64 launches of k_la_step."""
+    if not kernel_ms:
+        return None
+    dom = max(kernel_ms, key=kernel_ms.get)
+    flop, byts, bound = alg_work(dom, N, Q, D, H)
+    if nlml_only and dom in ("k_cholinv", "k_la_step"):
+        flop, byts = N ** 3 / 3.0 + 2.0 * N * N, 8.0 * N * N
+    ms = kernel_ms[dom]
+    if bound == "mfma":
+        ach = flop * P / (ms * 1e-3) / 1e12
+        return {"kernel": dom, "ms_per_call": ms, "bound": "mfma", "achieved": ach, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS}
+    ach = byts * P / (ms * 1e-3) / 1e9
+    return {"kernel": dom, "ms_per_call": ms, "bound": "hbm", "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+
+
 def csrc_digest():
     """sha256 over the device sources (medgp_amd/csrc/*.h, *.hip): identifies the kernels a PMC summary was taken from."""
     import glob
@@ -232,7 +250,8 @@ def other_configs(dev_index, seed, reps=5):
         ctx.profile_enable(False)
         f_alg = N ** 3 + 6 * N * N + 80 * Q * N * (N + 1) / 2
         out[name] = {"patients": P, "N": N, "D": D, "Q": Q, "R": R, "H": H, "ms_per_call": 1e3 * dt, "evals_per_s": P / dt,
-                     "frac_fp64_peak": f_alg * P / dt / 1e12 / FP64_PEAK_TFLOPS, "kernel_ms": prof}
+                     "frac_fp64_peak": f_alg * P / dt / 1e12 / FP64_PEAK_TFLOPS, "kernel_ms": prof,
+                     "dominant_kernel": leg_roofline(prof, N, Q, D, H, P)}
         ctx.close()
 
     for shp in shapes:
@@ -241,9 +260,6 @@ def other_configs(dev_index, seed, reps=5):
     guarded("config4_full_4096xN512_D24", lambda: config4_full(out, dev_index, seed))
     guarded("cohort_mode_kde_P4096_D24_one_cluster", lambda: cohort_kde(out, dev_index, seed))
     guarded("host_paths", lambda: host_paths(out, dev_index, seed))
-    # (last: its `before` variant holds 166 GB of per-entry matrices -- 300 entries at the leading dimension of the largest -- and a
-    #  process started while the driver is still reclaiming them pays seconds for its first allocations: the trainer leg behind it once
-    #  took 5.0 s of process wall for a 0.5 s loop)
     guarded("ragged_cohort_300_lognormal_D24", lambda: ragged_cohort(out, dev_index, seed))
     return out
 
@@ -262,9 +278,15 @@ def ragged_cohort(out, dev_index, seed, reps=5):
     f_alg = float(sum(n ** 3 + 6 * n ** 2 + 80 * Q * n * (n + 1) / 2 for n in ns.astype(np.float64)))
     slots = np.arange(P)
     res = {}
-    saved = {k: os.environ.get(k) for k in ("MEDGP_CLASS_STREAMS", "MEDGP_NO_CLASSES")}
+    saved = {k: os.environ.get(k) for k in ("MEDGP_CLASS_STREAMS", "MEDGP_NO_CLASSES", "MEDGP_MEM_BUDGET_GB")}
     try:
-        for name, env, r in (("after", {}, reps), ("one_stream", {"MEDGP_CLASS_STREAMS": "0"}, reps), ("before", {"MEDGP_NO_CLASSES": "1"}, 1)):
+        variants = [("after", {}, reps), ("one_stream", {"MEDGP_CLASS_STREAMS": "0"}, reps)]
+        if os.environ.get("MEDGP_BENCH_RAGGED_BEFORE"):
+            # rounds 1-4 behaviour, on request only: it needs 2 x 83 GB of per-entry matrices (300 entries at the leading dimension of the
+            # largest), and memory a process has used is wiped by the driver before the next process gets it -- every run started behind
+            # this leg (the driver's N = 2, 4, 8 runs; a user's trainer) then waits seconds for its allocations (scratch/alloc_dirty.hip)
+            variants.append(("before", {"MEDGP_NO_CLASSES": "1", "MEDGP_MEM_BUDGET_GB": "200"}, 1))
+        for name, env, r in variants:
             for k in saved:
                 os.environ.pop(k, None)
             os.environ.update(env)
@@ -279,7 +301,7 @@ def ragged_cohort(out, dev_index, seed, reps=5):
                 ctx.nlml_grad(slots, th, True)
             dt = (time.perf_counter() - t0) / r
             res[name] = {"ms_per_call": 1e3 * dt, "evals_per_s": P / dt, "frac_fp64_peak": f_alg / dt / 1e12 / FP64_PEAK_TFLOPS,
-                         "plan_count_blocks_route": ctx.last_plan()}
+                         "plan_count_blocks_route": ctx.last_plan(), "alloc_s": ctx.alloc_stats()[0], "arena_gb": ctx.alloc_stats()[2] / 2 ** 30}
             ctx.close()
     finally:
         for k, v in saved.items():
@@ -287,7 +309,10 @@ def ragged_cohort(out, dev_index, seed, reps=5):
             if v is not None:
                 os.environ[k] = v
     out["ragged_cohort_300_lognormal_D24"] = {"patients": P, "D": D, "Q": Q, "R": R, "n_median": int(np.median(ns)), "n_max": int(ns.max()),
-                                              "sum_F_alg": f_alg, **res, "speedup_vs_before": res["before"]["ms_per_call"] / res["after"]["ms_per_call"]}
+                                              "sum_F_alg": f_alg, **res,
+                                              "before_recorded": {"ms_per_call": 572.5, "source": "rounds 1-4 routing (MEDGP_NO_CLASSES=1), BENCH_r05.json / round-6 box; "
+                                                                  "re-run with MEDGP_BENCH_RAGGED_BEFORE=1 (maps 166 GB)"},
+                                              "speedup_vs_before": (res["before"]["ms_per_call"] if "before" in res else 572.5) / res["after"]["ms_per_call"]}
 
 
 def screening(out, dev_index, seed, reps):
@@ -313,7 +338,17 @@ def screening(out, dev_index, seed, reps):
     prof = {k: round(v[0], 4) for k, v in ctx.profile_read().items() if v[1] > 0}
     out["screening_1000xN512_D24_nlml_only"] = {"evaluations": P, "N": N, "D": D, "ms_per_call": 1e3 * dt, "evals_per_s": P / dt,
                                                 "frac_fp64_peak": (N ** 3 / 3 + 2 * N * N + 40 * Q * N * (N + 1) / 2) * P / dt / 1e12 / FP64_PEAK_TFLOPS,
-                                                "kernel_ms": prof}
+                                                "kernel_ms": prof, "dominant_kernel": leg_roofline(prof, N, Q, D, synth.num_hyp(7, Q, D, R), P, nlml_only=True)}
+    # the same 1000 evaluations through medgp_screen (the entry point the trainer uses: theta block uploaded once, chunks queued without
+    # a host wait)
+    th1 = th
+    ctx.screen(np.zeros(1, dtype=np.int32), th1)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.screen(np.zeros(1, dtype=np.int32), th1)
+    dts = (time.perf_counter() - t0) / reps
+    out["screening_1000xN512_D24_nlml_only"]["medgp_screen_ms_per_call"] = 1e3 * dts
+    out["screening_1000xN512_D24_nlml_only"]["medgp_screen_evals_per_s"] = P / dts
     ctx.close()
 
 
@@ -371,7 +406,9 @@ def host_paths(out, dev_index, seed):
         m2 = re.search(r"lock-step optimisation: ([0-9.e+-]+) s wall \(([0-9.e+-]+) s waiting for the device", r.stdout)
         m3 = re.search(r"continuous admission: (\d+) patients through (\d+) resident slots in (\d+) admissions \(([0-9.e+-]+) s, of which screening ([0-9.e+-]+) s for (\d+) nlml-only", r.stdout)
         m4 = re.search(r"outside admissions: ([0-9.e+-]+); of the whole loop: ([0-9.e+-]+)", r.stdout)
+        m5 = re.search(r"device memory: ([0-9.e+-]+) s in (\d+) management calls", r.stdout)
         out["train_cohort_2048xN512_D24_real_budget"] = {
+            "alloc_s": float(m5.group(1)) if m5 else None,
             "patients": P2, "N": N, "D": D, "random_init_num": 1000, "top_iteration_num": 40, "iteration_num_per_update": 30,
             "process_wall_s": wall, "gradient_evaluations": int(m1.group(1)) if m1 else None, "lockstep_batches": int(m1.group(2)) if m1 else None,
             "loop_s": float(m2.group(1)) if m2 else None, "device_wait_s": float(m2.group(2)) if m2 else None,
@@ -391,22 +428,33 @@ def host_paths(out, dev_index, seed):
                               opt=dict(random_init_num=1000, top_iteration_num=40, iteration_num_per_update=30))
         plist3 = os.path.join(tmp, "ragged_pans.txt")
         open(plist3, "w").write("\n".join(pans3) + "\n")
-        t0 = time.perf_counter()
-        r = subprocess.run([os.path.join(host, "medgp_train"), "--cfg", ex3["cfg"], "--pan-list", plist3, "--resident", "512", "--device", str(dev_index)],
-                           capture_output=True, text=True, timeout=900)
-        wall = time.perf_counter() - t0
-        if r.returncode != 0:
-            raise RuntimeError("medgp_train (ragged, real budget) rc %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:]))
-        m1 = re.search(r"optimization finished: (\d+) nlml\+grad evaluations in (\d+) lock-step batches", r.stdout)
-        m3 = re.search(r"continuous admission: (\d+) patients through (\d+) resident slots in (\d+) admissions \(([0-9.e+-]+) s, of which screening ([0-9.e+-]+) s for (\d+) nlml-only", r.stdout)
-        m4 = re.search(r"outside admissions: ([0-9.e+-]+); of the whole loop: ([0-9.e+-]+)", r.stdout)
+        def ragged_run():
+            for f in os.listdir(ex3["dirs"]["train"]):
+                if f.startswith("train_"):
+                    os.remove(os.path.join(ex3["dirs"]["train"], f))
+            t0 = time.perf_counter()
+            r = subprocess.run([os.path.join(host, "medgp_train"), "--cfg", ex3["cfg"], "--pan-list", plist3, "--resident", "512", "--device", str(dev_index)],
+                               capture_output=True, text=True, timeout=900)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise RuntimeError("medgp_train (ragged, real budget) rc %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:]))
+            m1 = re.search(r"optimization finished: (\d+) nlml\+grad evaluations in (\d+) lock-step batches", r.stdout)
+            m3 = re.search(r"continuous admission: (\d+) patients through (\d+) resident slots in (\d+) admissions \(([0-9.e+-]+) s, of which screening ([0-9.e+-]+) s for (\d+) nlml-only", r.stdout)
+            m4 = re.search(r"outside admissions: ([0-9.e+-]+); of the whole loop: ([0-9.e+-]+)", r.stdout)
+            m5 = re.search(r"device memory: ([0-9.e+-]+) s in (\d+) management calls \(([0-9.e+-]+) s of it announcing the sizes up front\), ([0-9.e+-]+) GB mapped", r.stdout)
+            return {"process_wall_s": wall, "gradient_evaluations": int(m1.group(1)) if m1 else None,
+                    "lockstep_batches": int(m1.group(2)) if m1 else None, "screening_s": float(m3.group(5)) if m3 else None,
+                    "screening_evaluations": int(m3.group(6)) if m3 else None,
+                    "gradient_evals_per_s_outside_admissions": float(m4.group(1)) if m4 else None,
+                    "alloc_s": float(m5.group(1)) if m5 else None, "alloc_calls": int(m5.group(2)) if m5 else None,
+                    "reserve_plan_s": float(m5.group(3)) if m5 else None, "arena_gb": float(m5.group(4)) if m5 else None,
+                    "trained": sum(open(os.path.join(ex3["dirs"]["train"], f"train_flag_{p}.txt")).read().strip() == "1" for p in pans3)}
+        first = ragged_run()
+        second = ragged_run()     # the same run again: the two must agree (round 5's varied 2 x with what the device memory had been used for)
         out["train_cohort_512_lognormal_D24_real_budget"] = {
             "patients": P3, "n_median": int(np.median(ns3)), "n_max": int(max(ns3)), "D": D, "random_init_num": 1000, "top_iteration_num": 40,
-            "iteration_num_per_update": 30, "process_wall_s": wall, "gradient_evaluations": int(m1.group(1)) if m1 else None,
-            "lockstep_batches": int(m1.group(2)) if m1 else None, "screening_s": float(m3.group(5)) if m3 else None,
-            "screening_evaluations": int(m3.group(6)) if m3 else None,
-            "gradient_evals_per_s_outside_admissions": float(m4.group(1)) if m4 else None,
-            "trained": sum(open(os.path.join(ex3["dirs"]["train"], f"train_flag_{p}.txt")).read().strip() == "1" for p in pans3)}
+            "iteration_num_per_update": 30, **first, "repeat": second,
+            "repeat_wall_ratio": second["process_wall_s"] / first["process_wall_s"]}
         # ---- f3: 64 test patients, D = 4, N 120 .. 200, both passes (with / without the online hyper updates)
         P, D, Q, R = 64, 4, 3, 2
         pans = [f"C{k:03d}" for k in range(P)]
@@ -502,6 +550,30 @@ def cohort_kde(out, dev_index, seed):
                                                      "gaussian_pair_terms_per_s": ns * Pc * Pc / (kms * 1e-3)}
 
 
+def resolve_launch(gpus, env, argv, run=None):
+    """None: go on in this process.  Otherwise the exit code to leave with: 2 after a mismatch between --gpus and the launcher's
+    WORLD_SIZE (message on stderr, no JSON line), or the exit code of the N-rank launch this process started and waited for."""
+    under_launcher = all(k in env for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
+    if under_launcher:
+        if int(env["WORLD_SIZE"]) != gpus:
+            if env.get("RANK", "0") == "0":
+                print(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={env['WORLD_SIZE']} ranks; refusing to print a line whose n_gpus "
+                      f"differs from --gpus", file=sys.stderr, flush=True)
+            return 2
+        return None
+    if gpus <= 1:
+        return None
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"bench.py: --gpus {gpus} without a launcher: starting {gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return (run or subprocess.call)(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -524,6 +596,14 @@ def main():
                     help="process-group backend for N > 1: auto = nccl (RCCL) with one rank per GPU, gloo when ranks share GPUs")
     ap.add_argument("--dump-results", default=None, help="write this rank's (global patient ids, nlml, gradient row sums) to <path>.rank<r>.npz")
     args = ap.parse_args()
+
+    # --gpus N is the contract: a line whose n_gpus differs from it must never be printed (verdict r5 item 7).  Under a launcher
+    # (torch.distributed.run's environment) N must equal WORLD_SIZE.  Without one and N > 1 this process starts the N ranks ITSELF --
+    # as children of a parent that has not touched the GPU (no torch import above this line) and only waits and passes their output
+    # through; the reference's fan-out being replaced is one scheduler job per patient (medgpc/util/run_exp_generator.py:213-260).
+    rc = resolve_launch(args.gpus, os.environ, sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
 
     import torch
     import medgp_amd
@@ -678,6 +758,11 @@ def main():
             achieved = byts * P / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
         traffic, traffic_prov = pmc_traffic(dom, P, N)
+        # the HBM side of the same kernel (verdict r5 item 6): measured traffic / launch time against the 8 TB/s spec, and against the
+        # algorithmic bytes (ratio > 1 = re-reads: the left-looking history of k_cholinv)
+        roof.update({"hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "hbm_achieved_GBs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+                     "traffic_ratio": (traffic / (byts * P)) if traffic and byts else None})
         roof.update({"traffic": traffic, "traffic_provenance": traffic_prov, "kernel": dom, "avg_launch_ms": avg_ms,
                      "alg_per_patient": {"flop": flop, "bytes": byts},
                      "kernel_ms_per_step": {k: round(v[0] / n_split, 4) for k, v in prof_all.items() if v[1] > 0},

@@ -54,7 +54,7 @@ typedef struct medgp_ctx medgp_ctx;
 #define MEDGP_FLAG_KEEP_FACTOR 2
 
 /* ABI version, bumped on any signature change */
-int medgp_abi_version(void);
+int medgp_abi_version(void);   /* 3: medgp_reserve_plan, medgp_alloc_stats (round 6) */
 
 /* number of visible HIP devices (0 if none; never initialises a context) */
 int medgp_device_count(void);
@@ -82,9 +82,28 @@ int medgp_set_stream(medgp_ctx *ctx, void *hip_stream);
  * Replaces the per-evaluation new[]/delete[] of N*N buffers, ref: core/gp_regression.cpp:102-117,
  * inference/c_inference_exact.cpp:66-68,168. Existing patients are discarded.
  * The per-entry matrices (two padded n x n fp64 matrices per batch entry) are allocated here when max_batch x max_n^2 of them stay
- * below 8 GB; beyond that (a cohort whose largest patient is far above the rest) they are grown by the calls to what their size
- * classes need (see medgp_last_plan) -- a call that grows them waits for the device once and drops the factors of earlier calls. */
+ * below 8 GB; beyond that (a cohort whose largest patient is far above the rest) they are sized once by medgp_reserve_plan from the
+ * patients' sizes, or grown by the calls to what their size classes need (see medgp_last_plan) -- a call that outgrows a buffer waits
+ * for this context's streams (not the device), replaces it and drops the factors of earlier calls.  A call whose matrices exceed the memory budget (64 GB, at most 70 % of what the device has free;
+ * MEDGP_MEM_BUDGET_GB) is run as consecutive waves of size classes that reuse the arenas; calls whose OUTPUTS need every entry's matrix
+ * afterwards (MEDGP_FLAG_KEEP_FACTOR, medgp_factor_batch, medgp_fit_predict_batch) fail with MEDGP_ERR_CAPACITY instead. */
 int medgp_reserve(medgp_ctx *ctx, int max_slots, int max_n, int max_batch);
+
+/* Announce the sizes of the patients that will be resident together (n[count] observation counts, any order) and the width of the
+ * random-initialisation screening (ninit hyper vectors per patient, 0 = none): the per-entry arenas are mapped ONCE to the high-water
+ * mark of (a) one nlml + gradient call over them and (b) the chunks medgp_screen forms of them, so that no later call has to obtain
+ * device memory.  Optional -- without it the buffers grow with the calls -- but on this platform obtaining memory that an earlier
+ * process has used can take seconds (the driver wipes it first; 0.27 s per GB was measured), and a long-lived trainer wants that wait
+ * once, before its loop, not inside it, and for as few bytes as its calls really need.  A cohort host has the sizes before its first call: the reference's
+ * job generator reads them to bucket patients by N (ref: medgpc/util/run_exp_generator.py:213-260, scripts/slurm_della.json:6-62),
+ * medgp_train takes them from its patient list.  Replaces nothing the reference allocates ahead: it news / deletes its N x N buffers
+ * per evaluation (ref: core/gp_regression.cpp:102-117, inference/c_inference_exact.cpp:66-68,168). */
+int medgp_reserve_plan(medgp_ctx *ctx, int count, const int32_t *n, int ninit);
+
+/* Memory-management accounting of the context: wall seconds spent obtaining / releasing device memory so far, the number of such
+ * calls, and the bytes currently mapped into the per-entry arenas.  Any pointer may be NULL.  (bench.py and medgp_train report it as
+ * `alloc_s`: time the host spent waiting for memory instead of queueing work.) */
+int medgp_alloc_stats(const medgp_ctx *ctx, double *seconds, int64_t *calls, int64_t *bytes_mapped);
 
 /* Upload one patient (meta[i] in [0,D), t = time stamps, y = z-scored values; host pointers, copied).
  * Replaces c_objective_one's constructor, ref: util/c_objective_one.cpp:23-36 and

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # every symbol include/medgp_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "medgp_abi_version", "medgp_device_count", "medgp_create", "medgp_destroy", "medgp_last_error",
-    "medgp_num_hyp", "medgp_set_pi", "medgp_set_stream", "medgp_reserve", "medgp_set_patient",
+    "medgp_num_hyp", "medgp_set_pi", "medgp_set_stream", "medgp_reserve", "medgp_reserve_plan", "medgp_alloc_stats", "medgp_set_patient",
     "medgp_set_patients", "medgp_set_prior", "medgp_set_priors", "medgp_host_alloc", "medgp_host_free", "medgp_nlml_grad_async",
     "medgp_wait", "medgp_nlml_grad", "medgp_screen", "medgp_nlml_grad_device", "medgp_get_factor",
     "medgp_factor", "medgp_factor_batch", "medgp_pin_route", "medgp_last_plan", "medgp_fit_predict", "medgp_fit_predict_batch", "medgp_synchronize", "medgp_profile_enable", "medgp_profile_num_kernels",
@@ -70,6 +70,8 @@ def load():
     lib.medgp_set_pi.argtypes = [vp, C.c_double]
     lib.medgp_set_stream.argtypes = [vp, vp]
     lib.medgp_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.medgp_reserve_plan.argtypes = [vp, C.c_int, i32p, C.c_int]
+    lib.medgp_alloc_stats.argtypes = [vp, dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.medgp_set_patient.argtypes = [vp, C.c_int, C.c_int, i32p, fp, fp]
     lib.medgp_set_patients.argtypes = [vp, C.c_int, i32p, C.POINTER(C.c_int64), i32p, fp, fp]
     lib.medgp_set_prior.argtypes = [vp, C.c_int, u8p, i32p, u8p, fp, fp]
@@ -179,6 +181,18 @@ class Context:
 
     def reserve(self, max_slots, max_n, max_batch):
         self._chk(self._lib.medgp_reserve(self._h, int(max_slots), int(max_n), int(max_batch)))
+
+    def reserve_plan(self, sizes, ninit=0):
+        """medgp_reserve_plan: announce the sizes of the patients that will be resident together (and the width of the screening):
+        the per-entry arenas are mapped once to what the largest call over them needs."""
+        sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+        self._chk(self._lib.medgp_reserve_plan(self._h, int(sizes.shape[0]), _ptr(sizes, C.c_int32), int(ninit)))
+
+    def alloc_stats(self):
+        """(seconds spent in device-memory management calls, number of such calls, bytes mapped into the per-entry arenas)"""
+        s, n, b = C.c_double(0.0), C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.medgp_alloc_stats(self._h, C.byref(s), C.byref(n), C.byref(b)))
+        return s.value, n.value, b.value
 
     def set_patient(self, slot, meta, t, y):
         t = np.ascontiguousarray(t, dtype=np.float32)

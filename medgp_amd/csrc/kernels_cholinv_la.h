@@ -85,7 +85,7 @@ struct LaArgs {
     int *flag;            // [batch] step counter of the diagonal chain: k + 1 once the D workgroup of step k is done (parking, below)
     int nbmax;            // 64-blocks of the largest patient of the batch
     int maxslice;         // slices per row block the scratch is dimensioned for
-    int rows;             // row blocks the scratch is dimensioned for (2 nbmax + 1)
+    int rows;             // row blocks the scratch is dimensioned for: 2 nbmax + 1, or nbmax + 1 for an nlml-only call (no U row blocks)
     int ring;             // index mask of the chain's hand-off slabs xk2 / pnx / dterm / dsum: 1 = by step parity
     int nbatch;           // entries of the class.  The grids' x extent is nbatch, or nbatch | 1 for a class whose entries differ in size:
                           // workgroup ids (y * extent + x) go round-robin over the 8 XCDs, so with an extent of 2, 4, 8, ... every entry's
@@ -94,7 +94,7 @@ struct LaArgs {
                           // 2.74 ms).  An odd extent puts every entry on all XCDs; the workgroups of the padding column exit.
 };
 
-// row block index inside the scratch: M_i -> i, U_rho -> nbmax + rho, Y -> 2 nbmax
+// row block index inside the scratch: M_i -> i, U_rho -> nbmax + rho, Y -> the last row block (2 nbmax, or nbmax without U rows)
 struct LaRow {
     int kind;             // 0 = M, 1 = U, 2 = Y
     int blk;              // i or rho
@@ -121,7 +121,7 @@ __device__ __forceinline__ double *la_row_base(const MedgpDev &L, const LaArgs &
     return A.ybuf + (size_t)b * 64 * ld;
 }
 __device__ __forceinline__ int la_row_index(const LaArgs &A, LaRow r) {
-    return r.kind == 0 ? r.blk : (r.kind == 1 ? A.nbmax + r.blk : 2 * A.nbmax);
+    return r.kind == 0 ? r.blk : (r.kind == 1 ? A.nbmax + r.blk : A.rows - 1);
 }
 __device__ __forceinline__ double *la_part(const LaArgs &A, int b, int parity, LaRow r, int slice) {
     return A.part + ((((size_t)b * 2 + parity) * A.rows + la_row_index(A, r)) * A.maxslice + slice) * 4096;

@@ -202,7 +202,7 @@ __device__ inline void prior_apply(const MedgpPrior &p, double hv, double pi, bo
         lp = lp - log(2 * pi * p.p1) / 2.0;
         dlp = -1.0 * (hv - p.p0) / p.p1;
     } else if (p.type == 2) {
-        lp = (-1.0 * fabs(hv - p.p0) / p.p1) - log((double)(2 * p.p1));
+        lp = (-1.0 * fabs(hv - p.p0) / p.p1) - (double)p.lg2b;   // (float log, as the reference: MedgpPrior::lg2b)
         if (hv == p.p0) dlp = 0.0;
         else dlp = -1.0 * ((hv > p.p0) ? 1.0 : -1.0) / p.p1;
     } else return;

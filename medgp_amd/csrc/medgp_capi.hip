@@ -13,6 +13,7 @@
 #include "kernels_cohort.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -41,7 +42,8 @@ struct SizeClass {
     int b0 = 0, count = 0;     // internal entries [b0, b0 + count)
     int nbmax = 1;             // 64-blocks of the class's largest entry
     int ld = 64;               // leading dimension of the class view
-    size_t off_mat = 0, off_vec = 0, off_tab = 0, off_slab = 0;   // offsets (doubles) of the class inside Kmat/Linv, z/alpha/wdiag, cs/sn, slab
+    int wave = 0;              // memory wave of the call the class runs in (round 6; BatchPlan::nwaves)
+    size_t off_mat = 0, off_vec = 0, off_tab = 0, off_slab = 0;   // offsets (doubles) of the class inside Kmat/Linv, z/alpha/wdiag, cs/sn, slab (relative to its wave: waves reuse the arenas)
     long long tsum = 0;        // sum of the cost model over its entries (route rule)
     int route = ROUTE_WG84;    // last route taken (diagnostics: medgp_last_plan)
 };
@@ -51,9 +53,39 @@ struct BatchPlan {
     std::vector<int> inv;      // caller index -> internal index
     std::vector<int> en;       // n of every entry, internal order
     std::vector<SizeClass> cls;
-    size_t need_mat = 0, need_vec = 0, need_tab = 0, need_slab = 0;   // doubles the call needs of each arena
+    size_t need_mat = 0, need_vec = 0, need_tab = 0, need_slab = 0;   // doubles the call needs of each arena (largest wave)
+    // Memory waves (round 6): a call whose per-entry matrices exceed the context's budget (512 resident patients of N ~ 6000 would
+    // need 296 GB) is run as consecutive WAVES of whole size classes that each fit it; the waves reuse the arenas in stream order.
+    int nwaves = 1;
+    bool with_u = true;        // laid out for Kmat AND Linv (false: an nlml-only plan, 8 ld^2 bytes per entry instead of 16)
 };
 constexpr int kAuxStreams = 4;
+
+// ---- device memory arenas (round 6) -----------------------------------------------------------------------------------------
+// The per-entry buffers of a context live in ARENAS: one hipMalloc block each, sized ONCE where the caller can say what it will need
+// (medgp_reserve for capacities below 8 GB of matrices -- every BASELINE configuration; medgp_reserve_plan from the patients' sizes)
+// and otherwise replaced by a larger block when a call outgrows it.  What round 6 measured about memory on this platform
+// (scratch/alloc_cost.hip, alloc_dirty.hip, vmm_repro.hip, vmm_stress.hip -> profiles/r06_memory_findings.txt; MI355X, ROCm 7.2):
+//   * hipMalloc / hipFree cost microseconds on a fresh device (48 GB: 0.3 ms), but memory that has been USED and freed -- by this or
+//     an earlier process -- is wiped by the driver, and an allocation that is handed such memory waits for the wipe: 24 GB after
+//     another process had freed 250 GB took 6.5 s, a 100 GB block 2-3 s on its second use inside one process.  Rounds 1-5 grew the
+//     arenas by hipDeviceSynchronize + hipFree + hipMalloc(1.5 x) and sized screening chunks at 26 + 9 GB: BENCH_r05's 9.5 s of
+//     screening on the driver's box against 5.1 s on the builder's was this.  The cure is to obtain LITTLE memory, ONCE: nlml-only
+//     plans have no Linv (half the bytes), screening chunks hold 2 GB instead of 48, the trainer announces its sizes before its loop.
+//   * Virtual-memory management (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess: grow in place, never free, never
+//     move) was built first and REMOVED: on this runtime hipMemSetAccess on the second chunk of a range fails with "invalid argument"
+//     for some size / address patterns (24 MB then 2 MB; 2 MB then 24 MB with alignment 0), a reservation is booked against the
+//     device's free-memory counter as if it were memory (one 256 GB reservation: "Free memory set to zero", every later call fails),
+//     and re-mapping chunks into a larger range left stale translations behind -- a later range read another arena's data
+//     (vmm_stress: mismatches in every arena after the first).  Plain blocks it is.
+//   * A growth waits for the CONTEXT's streams, not the device (hipDeviceSynchronize stalled every other context / rank sharing the
+//     GPU), asks for 1.5 x and retries with exactly what is needed if that fails.
+struct Arena {
+    char *base = nullptr;
+    size_t mapped = 0;   // bytes usable
+};
+constexpr size_t kArenaEager = (size_t)8 << 30;
+enum ArenaId { AR_K = 0, AR_U, AR_Z, AR_ALPHA, AR_WDIAG, AR_CS, AR_SN, AR_SLAB, AR_LA_PART, AR_LA_SMALL, AR_COUNT };
 
 }  // namespace
 
@@ -101,10 +133,16 @@ struct medgp_ctx {
     std::vector<int> h_bslot;       // effective slots of the last call, CALLER order
     int last_nbatch = 0;
     BatchPlan plan;                 // of the last call
-    // arenas of the per-entry buffers (Kmat | Linv, z | alpha | wdiag, cs | sn, slab): what medgp_reserve's capacities would need at
-    // most (full_*), what is allocated (cap_*).  Up to kArenaEager bytes they are allocated by medgp_reserve; beyond that (a ragged
-    // cohort whose largest patient is far above the median: max_batch x max_n^2 would not fit 288 GB) they grow with the calls.
-    size_t full_mat = 0, full_vec = 0, full_tab = 0, full_slab = 0, cap_mat = 0, cap_vec = 0, cap_tab = 0, cap_slab = 0;
+    // arenas of the per-entry buffers (Kmat, Linv, z, alpha, wdiag, cs, sn, slab, look-ahead scratch): what medgp_reserve's capacities
+    // would need at most (full_*: the size of the address reservation).  Up to kArenaEager bytes they are mapped by medgp_reserve; beyond
+    // that (a ragged cohort whose largest patient is far above the median: max_batch x max_n^2 would not fit 288 GB) they grow with the
+    // calls or are sized once by medgp_reserve_plan (struct Arena).
+    size_t full_mat = 0, full_vec = 0, full_tab = 0, full_slab = 0;
+    Arena arena[AR_COUNT];
+    size_t mem_budget = (size_t)64 << 30;   // bytes of per-entry matrices one wave of a call may use (MEDGP_MEM_BUDGET_GB)
+    size_t screen_budget = (size_t)2 << 30; // the same for one chunk of medgp_screen (MEDGP_SCREEN_BUDGET_GB)
+    double alloc_s = 0.0;           // wall seconds inside device / pinned memory management calls (medgp_alloc_stats)
+    long long alloc_calls = 0;
     int *d_bpos = nullptr;
     int *d_tpos = nullptr;          // theta rows of the entries (medgp_screen), internal order
     bool tpos_on = false;
@@ -117,8 +155,7 @@ struct medgp_ctx {
     hipEvent_t ev_stage = nullptr;
     bool stage_pending = false;
     // scratch of the look-ahead multi-CU factorisation (kernels_cholinv_la.h), grown on demand
-    double *d_la_part = nullptr, *d_la_small = nullptr;
-    size_t la_part_cap = 0, la_small_cap = 0;
+    // (arena[AR_LA_PART], arena[AR_LA_SMALL])
     char *h_bounce = nullptr;        // pinned bounce buffer for the large device-to-host exports (factor matrices)
     size_t bounce_cap = 0;
     int *d_one_slot = nullptr;       // single-entry slot table for the caller-order re-factorisation of medgp_get_factor
@@ -171,16 +208,21 @@ int fail(medgp_ctx *c, int code, const char *fmt, ...) {
 template <typename T>
 int dalloc(medgp_ctx *c, T **p, size_t count) {
     void *q = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    c->alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    c->alloc_calls++;
     if (e != hipSuccess) return fail(c, MEDGP_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
     c->allocs.push_back(q);
     *p = (T *)q;
     return MEDGP_OK;
 }
 
+void arena_release(medgp_ctx *c, Arena &A);
 void free_all(medgp_ctx *c) {
     for (void *p : c->allocs) (void)hipFree(p);
     c->allocs.clear();
+    for (int i = 0; i < AR_COUNT; i++) arena_release(c, c->arena[i]);
 }
 
 int num_cov(int kidx, int Q, int D, int R) {
@@ -270,50 +312,69 @@ inline int size_bucket(int nb) { int j = 0; while ((1 << j) < nb) j++; return j;
 // N = 256 0.15, 512 0.70, 768 1.83, 1024 3.7; N = 8192: 1.05 s against 1.33 s measured).  Integer, so the route rule is exact.
 inline long long wg_cost(int nb) { return (long long)nb * nb * (nb + 17); }
 
-// Select the batch and lay out its plan.  caller_order: entries whose patient was not uploaded grouped by output use the caller-order
-// copy of the patient (slot + max_slots), so that the factor is the one the caller's order defines (no gradient on that copy).
-int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bool caller_order = false) {
-    if (nbatch < 1 || nbatch > c->max_batch) return fail(c, MEDGP_ERR_CAPACITY, "nbatch %d outside [1, %d]", nbatch, c->max_batch);
-    int mx = 0;
-    std::vector<int> eff(nbatch);
-    for (int b = 0; b < nbatch; b++) {
-        int s = slots[b];
-        if (s < 0 || s >= c->max_slots || c->h_n[s] < 0) return fail(c, MEDGP_ERR_ARG, "slots[%d] = %d is not a resident patient", b, s);
-        mx = std::max(mx, c->h_n[s]);
-        eff[b] = (caller_order && !c->h_perm_identity[s]) ? s + c->max_slots : s;
-    }
-    *max_n_out = mx;
-    bool same = (nbatch == c->last_nbatch) && std::memcmp(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch) == 0;
-    if (same) return MEDGP_OK;
-    std::memcpy(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch);
-    BatchPlan &P = c->plan;
+// Lay out the plan of a call from the sizes of its entries alone (en[b] = n of caller entry b): internal order, size classes, memory
+// waves, offsets, needs.  with_u: the call forms U = L^-T (gradient / factor outputs / predict); an nlml-only call touches neither
+// Linv nor the gradient slab.  Pure host arithmetic: medgp_reserve_plan runs it on announced sizes to find the high-water marks.
+void layout_plan(const medgp_ctx *c, const int *en, int nbatch, bool with_u, BatchPlan &P) {
     P.order.resize(nbatch); P.inv.resize(nbatch); P.en.resize(nbatch);
     P.cls.clear();
-    for (int b = 0; b < nbatch; b++) P.order[b] = b;
-    auto nof = [&](int b) { return c->h_n[slots[b]]; };
+    P.with_u = with_u;
+    int mx = 0;
+    for (int b = 0; b < nbatch; b++) { P.order[b] = b; mx = std::max(mx, en[b]); }
     const bool classes = !c->no_classes;
     // by 64-block count, largest first (what the hardware dispatches first runs longest: LPT inside every launch); ties keep the caller's order
-    if (classes) std::stable_sort(P.order.begin(), P.order.end(), [&](int a, int b) { return blocks64(nof(a)) > blocks64(nof(b)); });
+    if (classes) std::stable_sort(P.order.begin(), P.order.end(), [&](int a, int b) { return blocks64(en[a]) > blocks64(en[b]); });
     P.identity = true;
-    for (int i = 0; i < nbatch; i++) { P.inv[P.order[i]] = i; P.en[i] = nof(P.order[i]); P.identity = P.identity && P.order[i] == i; }
-    const size_t Q = c->Q, D = c->D;
-    size_t om = 0, ov = 0, ot = 0, os = 0;
+    for (int i = 0; i < nbatch; i++) { P.inv[P.order[i]] = i; P.en[i] = en[P.order[i]]; P.identity = P.identity && P.order[i] == i; }
+    const size_t Q = c->Q, D = c->D, bpe = with_u ? 16 : 8;   // bytes of per-entry matrices per ld^2
+    size_t om = 0, ov = 0, ot = 0, os = 0, wave_bytes = 0;
+    int wave = 0;
+    P.need_mat = P.need_vec = P.need_tab = P.need_slab = 0;
     for (int i = 0; i < nbatch;) {
         SizeClass k;
         k.b0 = i;
         const int bk = size_bucket(blocks64(P.en[i]));
-        int j = i;
-        while (j < nbatch && (!classes || size_bucket(blocks64(P.en[j])) == bk)) { k.tsum += wg_cost(blocks64(P.en[j])); k.nbmax = std::max(k.nbmax, blocks64(P.en[j])); j++; }
-        if (!classes) k.nbmax = blocks64(mx);
-        k.count = j - i;
+        k.nbmax = classes ? blocks64(P.en[i]) : blocks64(mx);   // (sorted: the first entry of a class is its largest)
         k.ld = 64 * k.nbmax;
+        // a class is cut where its matrices would exceed the budget of one wave (512 entries of N ~ 6000: 296 GB)
+        const size_t per = bpe * (size_t)k.ld * k.ld;
+        const int cmax = classes ? (int)std::max<size_t>(1, c->mem_budget / per) : nbatch;
+        int j = i;
+        while (j < nbatch && j - i < cmax && (!classes || size_bucket(blocks64(P.en[j])) == bk)) { k.tsum += wg_cost(blocks64(P.en[j])); j++; }
+        k.count = j - i;
+        const size_t kbytes = per * k.count;
+        if (classes && wave_bytes > 0 && wave_bytes + kbytes > c->mem_budget) { wave++; om = ov = ot = os = 0; wave_bytes = 0; }
+        k.wave = wave;
+        wave_bytes += kbytes;
         k.off_mat = om; k.off_vec = ov; k.off_tab = ot; k.off_slab = os;
         om += (size_t)k.count * k.ld * k.ld; ov += (size_t)k.count * k.ld; ot += (size_t)k.count * Q * k.ld;
-        os += (size_t)k.count * 3 * Q * (k.ld / 16 + D) * (k.ld / 64 + D);
+        if (with_u) os += (size_t)k.count * 3 * Q * (k.ld / 16 + D) * (k.ld / 64 + D);
+        P.need_mat = std::max(P.need_mat, om); P.need_vec = std::max(P.need_vec, ov); P.need_tab = std::max(P.need_tab, ot); P.need_slab = std::max(P.need_slab, os);
         P.cls.push_back(k);
         i = j;
     }
-    P.need_mat = om; P.need_vec = ov; P.need_tab = ot; P.need_slab = os;
+    P.nwaves = wave + 1;
+}
+
+// Select the batch and lay out its plan.  caller_order: entries whose patient was not uploaded grouped by output use the caller-order
+// copy of the patient (slot + max_slots), so that the factor is the one the caller's order defines (no gradient on that copy).
+int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bool caller_order, bool with_u) {
+    if (nbatch < 1 || nbatch > c->max_batch) return fail(c, MEDGP_ERR_CAPACITY, "nbatch %d outside [1, %d]", nbatch, c->max_batch);
+    int mx = 0;
+    std::vector<int> eff(nbatch), en(nbatch);
+    for (int b = 0; b < nbatch; b++) {
+        int s = slots[b];
+        if (s < 0 || s >= c->max_slots || c->h_n[s] < 0) return fail(c, MEDGP_ERR_ARG, "slots[%d] = %d is not a resident patient", b, s);
+        mx = std::max(mx, c->h_n[s]);
+        en[b] = c->h_n[s];
+        eff[b] = (caller_order && !c->h_perm_identity[s]) ? s + c->max_slots : s;
+    }
+    *max_n_out = mx;
+    bool same = (nbatch == c->last_nbatch) && c->plan.with_u == with_u && std::memcmp(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch) == 0;
+    if (same) return MEDGP_OK;
+    std::memcpy(c->h_bslot.data(), eff.data(), sizeof(int) * nbatch);
+    BatchPlan &P = c->plan;
+    layout_plan(c, en.data(), nbatch, with_u, P);
     // the tables travel through the pinned ring: no wait for the device (the lock-step optimiser changes the active set on
     // most steps; stream order puts the copy behind the kernels of the previous call that still read the old tables)
     const bool need_pos = !(P.identity && P.cls.size() == 1);
@@ -394,68 +455,96 @@ int d2h_pinned(medgp_ctx *c, const void *dev, size_t bytes, const char **out) {
     return MEDGP_OK;
 }
 
-// the arenas of the per-entry buffers, grown on demand (see medgp_ctx::full_mat); a growth waits for the device and drops the
-// factors of earlier calls
-constexpr size_t kArenaEager = (size_t)8 << 30;
-int ensure_arena(medgp_ctx *c, size_t need_mat, size_t need_vec, size_t need_tab, size_t need_slab) {
-    MedgpDev &L = c->dev;
-    auto grow = [&](size_t need, size_t full, size_t *cap, std::initializer_list<double **> bufs) -> int {
-        if (need <= *cap) return MEDGP_OK;
-        HIPCHK(c, hipDeviceSynchronize());
-        const size_t want = std::min(std::max(need, *cap + *cap / 2), std::max(full, need));
-        for (double **p : bufs) {
-            if (*p) {
-                (void)hipFree(*p);
-                c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), (void *)*p), c->allocs.end());
-                *p = nullptr;
-            }
-        }
-        *cap = 0;
-        for (double **p : bufs) { int rc = dalloc(c, p, want); if (rc) return rc; }
-        *cap = want;
-        c->last_has_inverse = false;
-        return MEDGP_OK;
-    };
-    int rc;
-    if ((rc = grow(need_mat, c->full_mat, &c->cap_mat, {&L.Kmat, &L.Linv}))) return rc;
-    if ((rc = grow(need_vec, c->full_vec, &c->cap_vec, {&L.z, &L.alpha, &L.wdiag}))) return rc;
-    if ((rc = grow(need_tab, c->full_tab, &c->cap_tab, {&L.cs, &L.sn}))) return rc;
-    if ((rc = grow(need_slab, c->full_slab, &c->cap_slab, {&L.slab}))) return rc;
+// ---- arenas: reserve once, map more behind what is there, never move (see struct Arena) ----------------------------------------
+struct AllocTimer {   // wall time of the memory-management calls, for medgp_alloc_stats
+    medgp_ctx *c;
+    std::chrono::steady_clock::time_point t0;
+    explicit AllocTimer(medgp_ctx *c_) : c(c_), t0(std::chrono::steady_clock::now()) {}
+    ~AllocTimer() { c->alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); c->alloc_calls++; }
+};
+
+void arena_release(medgp_ctx *c, Arena &A) {
+    AllocTimer tm(c);
+    if (A.base) (void)hipFree(A.base);
+    A = Arena{};
+}
+
+// every stream of the context is idle afterwards (NOT the device: other contexts / ranks that share it keep running)
+int sync_ctx_streams(medgp_ctx *c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < kAuxStreams; i++) if (c->aux[i]) HIPCHK(c, hipStreamSynchronize(c->aux[i]));
+    if (c->s_up) HIPCHK(c, hipStreamSynchronize(c->s_up));
+    if (c->s_down) HIPCHK(c, hipStreamSynchronize(c->s_down));
     return MEDGP_OK;
 }
 
-// scratch of the look-ahead factorisation for the classes of a call that take it (freed by free_all): one allocation pair, carved up
-// per class -- the classes run on different streams
-struct LaNeed { int count, nbmax, ld; LaArgs A; };
-int ensure_la(medgp_ctx *c, std::vector<LaNeed> &v) {
-    const size_t nring = 2;
-    size_t need_part = 0, need_small = 0;
-    auto part_of = [&](const LaNeed &e) { return (size_t)e.count * 2 * (2 * e.nbmax + 1) * ((e.nbmax + LA_SLICE - 1) / LA_SLICE) * 4096; };
-    auto small_of = [&](const LaNeed &e) { return (size_t)e.count * (64 * (size_t)e.ld + 5 * nring * 4096 + 2 * (size_t)((e.nbmax + LA_SLICE - 1) / LA_SLICE) * 4096 + 1); };
-    for (const LaNeed &e : v) { need_part += part_of(e); need_small += small_of(e); }
-    auto grow = [&](double **p, size_t *cap, size_t need) -> int {
-        if (need <= *cap) return MEDGP_OK;
-        HIPCHK(c, hipDeviceSynchronize());   // the old scratch may still be read by kernels queued on any of the context's streams
-        if (*p) {
-            (void)hipFree(*p);
-            c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), (void *)*p), c->allocs.end());
-            *p = nullptr; *cap = 0;
-        }
-        int rc = dalloc(c, p, need);
-        if (rc) return rc;
-        *cap = need;
+// make at least `bytes` of arena `id` usable.  exact: the caller knows this is the high-water mark (medgp_reserve, medgp_reserve_plan):
+// allocate just that; otherwise 1.5 x what was there (at most `limit` bytes, the most the capacities of medgp_reserve allow), with a
+// retry at exactly `bytes`.  *moved is set when the block was replaced: its contents are gone.
+int arena_ensure(medgp_ctx *c, int id, size_t bytes, size_t limit, bool exact, bool *moved) {
+    Arena &A = c->arena[id];
+    if (bytes <= A.mapped) return MEDGP_OK;
+    AllocTimer tm(c);
+    // nothing of this context may still read the old block (its streams, not the device: other contexts keep running)
+    const size_t old = A.mapped;
+    if (A.base) { int rc = sync_ctx_streams(c); if (rc) return rc; (void)hipFree(A.base); }
+    A = Arena{};
+    size_t want = exact ? bytes : std::max(bytes, old + old / 2);
+    if (limit >= bytes) want = std::min(want, limit);
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, want);
+    if (e != hipSuccess && want > bytes) { (void)hipGetLastError(); want = bytes; e = hipMalloc(&q, want); }   // near capacity the 1.5 x request can fail where `bytes` fits
+    if (e != hipSuccess) return fail(c, MEDGP_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+    A.base = (char *)q; A.mapped = want;
+    if (moved) *moved = true;
+    return MEDGP_OK;
+}
+
+// the arenas of the per-entry buffers of the batch views: doubles needed of Kmat, Linv (0: an nlml-only plan never touches it),
+// z / alpha / wdiag, cs / sn, slab.  exact: see arena_ensure.
+int ensure_arena(medgp_ctx *c, size_t need_k, size_t need_u, size_t need_vec, size_t need_tab, size_t need_slab, bool exact = false) {
+    MedgpDev &L = c->dev;
+    bool moved = false, mv;
+    int rc;
+    auto one = [&](int id, size_t need, size_t full, double **p) -> int {
+        mv = false;
+        if ((rc = arena_ensure(c, id, std::max<size_t>(need, 8) * sizeof(double), full * sizeof(double), exact, &mv))) return rc;
+        *p = (double *)c->arena[id].base;
+        moved = moved || mv;
         return MEDGP_OK;
     };
+    if ((rc = one(AR_K, need_k, c->full_mat, &L.Kmat))) return rc;
+    if ((rc = one(AR_U, need_u, c->full_mat, &L.Linv))) return rc;
+    if ((rc = one(AR_Z, need_vec, c->full_vec, &L.z))) return rc;
+    if ((rc = one(AR_ALPHA, need_vec, c->full_vec, &L.alpha))) return rc;
+    if ((rc = one(AR_WDIAG, need_vec, c->full_vec, &L.wdiag))) return rc;
+    if ((rc = one(AR_CS, need_tab, c->full_tab, &L.cs))) return rc;
+    if ((rc = one(AR_SN, need_tab, c->full_tab, &L.sn))) return rc;
+    if ((rc = one(AR_SLAB, need_slab, c->full_slab, &L.slab))) return rc;
+    if (moved) c->last_has_inverse = false;   // (the factors of earlier calls are gone)
+    return MEDGP_OK;
+}
+
+// scratch of the look-ahead factorisation for the classes of a wave that take it: two arenas, carved up per class -- the classes run
+// on different streams.  with_u = false (nlml only): no U row blocks, so the partial-sum slab holds nbmax + 1 row blocks, not 2 nbmax + 1.
+struct LaNeed { int count, nbmax, ld; LaArgs A; };
+inline size_t la_part_doubles(const LaNeed &e, bool with_u) { return (size_t)e.count * 2 * ((with_u ? 2 : 1) * e.nbmax + 1) * ((e.nbmax + LA_SLICE - 1) / LA_SLICE) * 4096; }
+inline size_t la_small_doubles(const LaNeed &e) { return (size_t)e.count * (64 * (size_t)e.ld + 5 * 2 * 4096 + 2 * (size_t)((e.nbmax + LA_SLICE - 1) / LA_SLICE) * 4096 + 1); }
+int ensure_la(medgp_ctx *c, std::vector<LaNeed> &v, bool with_u) {
+    const size_t nring = 2;
+    size_t need_part = 0, need_small = 0;
+    for (const LaNeed &e : v) { need_part += la_part_doubles(e, with_u); need_small += la_small_doubles(e); }
     int rc;
-    if ((rc = grow(&c->d_la_part, &c->la_part_cap, need_part))) return rc;
-    if ((rc = grow(&c->d_la_small, &c->la_small_cap, need_small))) return rc;
-    double *pp = c->d_la_part, *ps = c->d_la_small;
+    // (fallback blocks only: the old scratch may still be read by queued kernels -- arena_ensure waits for the context's streams)
+    if ((rc = arena_ensure(c, AR_LA_PART, need_part * sizeof(double), 0, false, nullptr))) return rc;
+    if ((rc = arena_ensure(c, AR_LA_SMALL, need_small * sizeof(double), 0, false, nullptr))) return rc;
+    double *pp = (double *)c->arena[AR_LA_PART].base, *ps = (double *)c->arena[AR_LA_SMALL].base;
     for (LaNeed &e : v) {
         LaArgs A{};
         const size_t nb = e.count;
         A.nbmax = e.nbmax;
         A.maxslice = (e.nbmax + LA_SLICE - 1) / LA_SLICE;
-        A.rows = 2 * e.nbmax + 1;
+        A.rows = (with_u ? 2 : 1) * e.nbmax + 1;
         A.ring = 1;
         A.nbatch = e.count;
         A.part = pp;
@@ -468,7 +557,7 @@ int ensure_la(medgp_ctx *c, std::vector<LaNeed> &v) {
         A.dpart = A.dsum + nb * nring * 4096;
         A.flag = (int *)(A.dpart + nb * 2 * A.maxslice * 4096);
         e.A = A;
-        pp += part_of(e); ps += small_of(e);
+        pp += la_part_doubles(e, with_u); ps += la_small_doubles(e);
     }
     return MEDGP_OK;
 }
@@ -625,16 +714,12 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
 // or 9/16 as above) -- i.e. when one of its entries on one workgroup would stick out of the average load per CU of everything that is
 // left.  For a uniform call S = n t and the rule is the old one (n <= 112 / 144); in a ragged call the heavy tail is peeled off class by
 // class until the rest is balanced.
-int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, int flag_grad, bool need_inverse, int min_n,
-                 double *nlml_dev, double *grad_dev, int32_t *status_dev, bool store_ukk = false) {
-    (void)max_n;
-    BatchPlan &P = c->plan;
-    { int rc = ensure_arena(c, P.need_mat, P.need_vec, P.need_tab, P.need_slab); if (rc) return rc; }
-    c->last_has_inverse = flag_grad || need_inverse;
+// routes of the classes of a plan (the rule above); returns the look-ahead scratch entries, la_of[i] = index into them or -1
+void choose_routes(const medgp_ctx *c, BatchPlan &P, std::vector<LaNeed> &las, std::vector<int> &la_of) {
     long long S = 0;
     for (const SizeClass &k : P.cls) S += k.tsum;
-    std::vector<LaNeed> las;
-    std::vector<int> la_of(P.cls.size(), -1);
+    las.clear();
+    la_of.assign(P.cls.size(), -1);
     for (size_t i = 0; i < P.cls.size(); i++) {
         SizeClass &k = P.cls[i];
         bool la = false;
@@ -657,31 +742,89 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
             k.route = shape == 44 ? ROUTE_WG44 : ROUTE_WG84;
         }
     }
-    if (!las.empty()) { int rc = ensure_la(c, las); if (rc) return rc; }
-    const bool fork = P.cls.size() > 1 && c->class_streams > 0 && c->aux[0];
-    if (fork) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-    const int nstr = std::min(c->class_streams, kAuxStreams);
-    bool used[kAuxStreams] = {false, false, false, false};
-    for (size_t i = 0; i < P.cls.size(); i++) {
-        const SizeClass &k = P.cls[i];
-        hipStream_t st = c->stream;
-        int ai = -1;
-        if (fork && i > 0) {   // class 0 (the largest entries) stays on the call's stream
-            ai = (int)((i - 1) % nstr);
-            st = c->aux[ai];
-            if (!used[ai]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); used[ai] = true; }
-        }
-        const MedgpDev V = class_view(c, k);
-        int rc = run_pipeline_one(c, st, V, k.count, k.nbmax, theta_dev, flag_grad, need_inverse, min_n, nlml_dev, grad_dev, status_dev, store_ukk,
-                                  P.en.data() + k.b0, k.route, la_of[i] >= 0 ? &las[la_of[i]].A : nullptr);
-        if (rc) return rc;
+}
+
+// what a plan needs of the look-ahead scratch arenas (doubles): the largest wave
+void la_needs(const BatchPlan &P, const std::vector<LaNeed> &las, const std::vector<int> &la_of, size_t *part, size_t *small) {
+    std::vector<size_t> wp(P.nwaves, 0), ws(P.nwaves, 0);
+    for (size_t i = 0; i < P.cls.size(); i++)
+        if (la_of[i] >= 0) { wp[P.cls[i].wave] += la_part_doubles(las[la_of[i]], P.with_u); ws[P.cls[i].wave] += la_small_doubles(las[la_of[i]]); }
+    *part = *small = 0;
+    for (int w = 0; w < P.nwaves; w++) { *part = std::max(*part, wp[w]); *small = std::max(*small, ws[w]); }
+}
+
+// End of the medgp_screen chunk that starts at entry e0 of the walk: entry e = (patient e / ninit of the walk, vector e % ninit); ns =
+// the patients' sizes in walk order (largest first).  A chunk holds at most max_batch entries and at most screen_budget bytes of
+// Gram matrices (8 ld^2 per entry: an nlml-only evaluation never forms U; ld taken at the upper end of the entry's size bucket, which
+// bounds the leading dimension of whatever class it lands in).  Entries of >= 45 blocks (64 MB of matrix each) take the look-ahead
+// schedule in any chunk this rule forms, and that schedule is saturated once a launch carries ~ 16 k block pairs (16 x N = 2048,
+// 4 x N = 4096, 2 x N = 5832: profiles/r04_route_table.txt): such a chunk is closed there -- N = 5832: 0.55 GB of
+// matrices + 0.28 GB of scratch per chunk where round 5 took 32 entries = 26 GB + 9 GB (obtaining that much memory cost seconds, see
+// struct Arena).  The budget (2 GB) still gives every size its efficient route: 1024 entries of N <= 512 (one workgroup each, two per
+// CU), 256 of N <= 1024 (one per CU), 64 of N <= 2048 (look-ahead schedule, saturated from 16 on).
+size_t screen_chunk_end(const medgp_ctx *c, const std::vector<int> &ns, int ninit, size_t e0, size_t total) {
+    size_t e = e0, bytes = 0;
+    long long work = 0;
+    while (e < total && (int)(e - e0) < c->max_batch) {
+        const int nb = blocks64(ns[e / ninit]);
+        const size_t ldb = (size_t)64 << size_bucket(nb), per = 8 * ldb * ldb;
+        if (e > e0 && bytes + per > c->screen_budget) break;
+        if (e > e0 && nb >= 45 && work >= 16384) break;
+        bytes += per; work += (long long)nb * nb; e++;
     }
-    if (fork)
-        for (int ai = 0; ai < nstr; ai++)
-            if (used[ai]) {
-                HIPCHK(c, hipEventRecord(c->ev_join[ai], c->aux[ai]));
-                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[ai], 0));
+    return e;
+}
+
+// persist: the caller reads per-entry buffers of ALL entries after the call (factor exports, k_predict): such a call must fit one wave.
+int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, int flag_grad, bool need_inverse, int min_n,
+                 double *nlml_dev, double *grad_dev, int32_t *status_dev, bool store_ukk = false, bool persist = false) {
+    (void)max_n; (void)nbatch;
+    BatchPlan &P = c->plan;
+    const bool forms_u = flag_grad || need_inverse || store_ukk;
+    if (forms_u && !P.with_u) return fail(c, MEDGP_ERR_ARG, "internal: plan laid out without Linv for a call that forms it");
+    if (persist && P.nwaves > 1)
+        return fail(c, MEDGP_ERR_CAPACITY, "the call's per-entry matrices exceed the memory budget of %zu GB (MEDGP_MEM_BUDGET_GB) and its outputs need all of them at once: split the call",
+                    c->mem_budget >> 30);
+    { int rc = ensure_arena(c, P.need_mat, P.with_u ? P.need_mat : 0, P.need_vec, P.need_tab, P.need_slab); if (rc) return rc; }
+    c->last_has_inverse = (flag_grad || need_inverse) && P.nwaves == 1;
+    std::vector<LaNeed> las;
+    std::vector<int> la_of;
+    choose_routes(c, P, las, la_of);
+    const int nstr = std::min(c->class_streams, kAuxStreams);
+    for (int w = 0; w < P.nwaves; w++) {
+        // this wave's classes [i0, i1) and their look-ahead scratch
+        size_t i0 = 0, i1;
+        while (i0 < P.cls.size() && P.cls[i0].wave != w) i0++;
+        i1 = i0;
+        while (i1 < P.cls.size() && P.cls[i1].wave == w) i1++;
+        std::vector<LaNeed> wl;
+        std::vector<int> wl_of(P.cls.size(), -1);
+        for (size_t i = i0; i < i1; i++) if (la_of[i] >= 0) { wl_of[i] = (int)wl.size(); wl.push_back(las[la_of[i]]); }
+        if (!wl.empty()) { int rc = ensure_la(c, wl, P.with_u); if (rc) return rc; }
+        const bool fork = i1 - i0 > 1 && c->class_streams > 0 && c->aux[0];
+        if (fork) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        bool used[kAuxStreams] = {false, false, false, false};
+        for (size_t i = i0; i < i1; i++) {
+            const SizeClass &k = P.cls[i];
+            hipStream_t st = c->stream;
+            int ai = -1;
+            if (fork && i > i0) {   // the wave's first class (its largest entries) stays on the call's stream
+                ai = (int)((i - i0 - 1) % nstr);
+                st = c->aux[ai];
+                if (!used[ai]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); used[ai] = true; }
             }
+            const MedgpDev V = class_view(c, k);
+            int rc = run_pipeline_one(c, st, V, k.count, k.nbmax, theta_dev, flag_grad, need_inverse, min_n, nlml_dev, grad_dev, status_dev, store_ukk,
+                                      P.en.data() + k.b0, k.route, wl_of[i] >= 0 ? &wl[wl_of[i]].A : nullptr);
+            if (rc) return rc;
+        }
+        if (fork)
+            for (int ai = 0; ai < nstr; ai++)
+                if (used[ai]) {
+                    HIPCHK(c, hipEventRecord(c->ev_join[ai], c->aux[ai]));
+                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[ai], 0));
+                }
+    }
     return MEDGP_OK;
 }
 
@@ -689,7 +832,7 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
 
 extern "C" {
 
-int medgp_abi_version(void) { return 2; }
+int medgp_abi_version(void) { return 3; }
 
 int medgp_device_count(void) {
     int n = 0;
@@ -729,6 +872,8 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     { const char *e = getenv("MEDGP_NO_CLASSES"); c->no_classes = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_WGRAD_DEEP"); c->wgrad_deep = e ? std::max(1, atoi(e)) : -1; }
     { const char *e = getenv("MEDGP_DEBUG_FAIL_ATTEMPTS"); c->dbg_fail = e ? atoi(e) : 0; }
+    { const char *e = getenv("MEDGP_MEM_BUDGET_GB"); if (e && atof(e) > 0) c->mem_budget = (size_t)(atof(e) * 1073741824.0); }
+    { const char *e = getenv("MEDGP_SCREEN_BUDGET_GB"); if (e && atof(e) > 0) c->screen_budget = (size_t)(atof(e) * 1073741824.0); }
     for (int i = 0; i < kAuxStreams; i++) {
         (void)hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
         (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
@@ -847,9 +992,19 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     L.slab_C = ldn / 64 + (int)D;
     L.slab_stride = (size_t)3 * Q * L.slab_R * L.slab_C;
     c->full_mat = B * ldn * ldn; c->full_vec = B * ldn; c->full_tab = B * Q * ldn; c->full_slab = B * L.slab_stride;
-    c->cap_mat = c->cap_vec = c->cap_tab = c->cap_slab = 0;
     L.Kmat = L.Linv = L.z = L.alpha = L.wdiag = L.cs = L.sn = L.slab = nullptr;
-    if (2 * c->full_mat * sizeof(double) <= kArenaEager && (rc = ensure_arena(c, c->full_mat, c->full_vec, c->full_tab, c->full_slab))) return rc;
+    {   // a wave of a call never uses more than the budget, and the budget never more than 70 % of what the device has free now
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 0) {
+            c->mem_budget = std::min(c->mem_budget, fr / 10 * 7);
+            c->screen_budget = std::min(c->screen_budget, c->mem_budget);
+        }
+    }
+    // every configuration whose capacities stay below 8 GB of matrices (all of BASELINE.json's) is mapped in full here; beyond that
+    // (a ragged cohort: max_batch x max_n^2 would not fit) the arenas start empty and grow with the calls, or with medgp_reserve_plan
+    if (2 * c->full_mat * sizeof(double) <= kArenaEager) rc = ensure_arena(c, c->full_mat, c->full_mat, c->full_vec, c->full_tab, c->full_slab, true);
+    else rc = ensure_arena(c, 0, 0, 0, 0, 0, true);   // (a token block each: the views never hold null pointers)
+    if (rc) return rc;
     double *xk;
     if ((rc = dalloc(c, &xk, B * 64 * 64))) return rc;
     L.xk = xk; L.jit = c->d_jit; L.bn = c->d_bn;
@@ -881,6 +1036,64 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
     if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; }
     c->stage_cap = 0;
     c->stage_pending = false;
+    return MEDGP_OK;
+}
+
+int medgp_reserve_plan(medgp_ctx *c, int count, const int32_t *n, int ninit) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
+    if (count < 1 || !n || ninit < 0) return fail(c, MEDGP_ERR_ARG, "medgp_reserve_plan: bad argument");
+    for (int i = 0; i < count; i++)
+        if (n[i] < 0 || n[i] > c->max_n) return fail(c, MEDGP_ERR_CAPACITY, "medgp_reserve_plan: n[%d] = %d outside [0, %d]", i, n[i], c->max_n);
+    HIPCHK(c, hipSetDevice(c->device));
+    // largest first, as medgp_screen walks them and as the lock-step trainer admits them
+    std::vector<int> ns(n, n + count);
+    std::stable_sort(ns.begin(), ns.end(), [](int a, int b) { return a > b; });
+    size_t nk = 0, nu = 0, nvec = 0, ntab = 0, nslab = 0, npart = 0, nsmall = 0;
+    BatchPlan P;
+    std::vector<LaNeed> las;
+    std::vector<int> la_of;
+    auto take = [&](const int *en, int nb, bool with_u) {
+        layout_plan(c, en, nb, with_u, P);
+        choose_routes(c, P, las, la_of);
+        size_t lp = 0, ls = 0;
+        la_needs(P, las, la_of, &lp, &ls);
+        nk = std::max(nk, P.need_mat); if (with_u) nu = std::max(nu, P.need_mat);
+        nvec = std::max(nvec, P.need_vec); ntab = std::max(ntab, P.need_tab); nslab = std::max(nslab, P.need_slab);
+        npart = std::max(npart, lp); nsmall = std::max(nsmall, ls);
+    };
+    // (a) one nlml + gradient call over the announced patients (the largest max_batch of them)
+    take(ns.data(), std::min(count, c->max_batch), true);
+    // (b) the chunks medgp_screen forms of them
+    if (ninit > 0) {
+        const size_t total = (size_t)count * ninit;
+        std::vector<int> en;
+        int last_first = -1, last_last = -1;
+        size_t last_cnt = 0;
+        for (size_t e0 = 0; e0 < total;) {
+            const size_t e = screen_chunk_end(c, ns, ninit, e0, total);
+            const int nf = ns[e0 / ninit], nl = ns[(e - 1) / ninit];
+            if (!(nf == nl && nf == last_first && nl == last_last && e - e0 == last_cnt)) {   // (runs of identical chunks: laid out once)
+                en.resize(e - e0);
+                for (size_t x = e0; x < e; x++) en[x - e0] = ns[x / ninit];
+                take(en.data(), (int)en.size(), false);
+                last_first = nf; last_last = nl; last_cnt = e - e0;
+            }
+            e0 = e;
+        }
+    }
+    int rc;
+    if ((rc = ensure_arena(c, nk, nu, nvec, ntab, nslab, true))) return rc;
+    if (npart && (rc = arena_ensure(c, AR_LA_PART, npart * sizeof(double), 0, true, nullptr))) return rc;
+    if (nsmall && (rc = arena_ensure(c, AR_LA_SMALL, nsmall * sizeof(double), 0, true, nullptr))) return rc;
+    return MEDGP_OK;
+}
+
+int medgp_alloc_stats(const medgp_ctx *c, double *seconds, int64_t *calls, int64_t *bytes_mapped) {
+    if (!c) return MEDGP_ERR_ARG;
+    if (seconds) *seconds = c->alloc_s;
+    if (calls) *calls = c->alloc_calls;
+    if (bytes_mapped) { int64_t b = 0; for (int i = 0; i < AR_COUNT; i++) b += (int64_t)c->arena[i].mapped; *bytes_mapped = b; }
     return MEDGP_OK;
 }
 
@@ -1037,7 +1250,7 @@ int upload_priors(medgp_ctx *c, int nrows, const int32_t *slots, const uint8_t *
             if (type[h] < -1 || type[h] > 2) return fail(c, MEDGP_ERR_ARG, "prior type[%zu] = %d unsupported (KDE prior type 3 is never constructed by the reference's mains)", h, type[h]);
     HIPCHK(c, hipSetDevice(c->device));
     if ((size_t)nrows > c->prior_stage_rows) {
-        HIPCHK(c, hipDeviceSynchronize());
+        { int rcs = sync_ctx_streams(c); if (rcs) return rcs; }   // (the context's streams, not the device: other contexts keep running)
         for (void *q : {(void *)c->d_prior_stage, (void *)c->d_prior_slots})
             if (q) { (void)hipFree(q); c->allocs.erase(std::remove(c->allocs.begin(), c->allocs.end(), q), c->allocs.end()); }
         c->d_prior_stage = nullptr; c->d_prior_slots = nullptr; c->prior_stage_rows = 0;
@@ -1058,7 +1271,10 @@ int upload_priors(medgp_ctx *c, int nrows, const int32_t *slots, const uint8_t *
         for (int h = 0; h < H; h++) {
             MedgpPrior p{};
             const size_t e = (size_t)k * H + h;
-            if (flag) { p.p0 = p0[e]; p.p1 = p1[e]; p.type = (int8_t)type[e]; p.flag = flag[e] ? 1 : 0; p.is_exp = is_exp[e] ? 1 : 0; }
+            if (flag) {
+                p.p0 = p0[e]; p.p1 = p1[e]; p.type = (int8_t)type[e]; p.flag = flag[e] ? 1 : 0; p.is_exp = is_exp[e] ? 1 : 0;
+                if (type[e] == 2) p.lg2b = logf(2.0f * p1[e]);   // the reference's float log (MedgpPrior::lg2b)
+            }
             else p.type = -1;
             hp[e] = p;
         }
@@ -1102,8 +1318,8 @@ int medgp_nlml_grad_device(medgp_ctx *c, int nbatch, const int32_t *slots, const
     int max_n = 0, rc;
     // factor wanted but no gradient: patients that were not uploaded grouped by output are evaluated in the CALLER's order,
     // so that L^-1 is the factor the reference would hand to GP_Regression::predict (ref: core/gp_regression.cpp:181-196)
-    if ((rc = set_batch(c, nbatch, slots, &max_n, keep && !grad))) return rc;
-    return run_pipeline(c, nbatch, max_n, theta_dev, grad, keep, 3, nlml_dev, grad_dev, status_dev);
+    if ((rc = set_batch(c, nbatch, slots, &max_n, keep && !grad, grad || keep))) return rc;
+    return run_pipeline(c, nbatch, max_n, theta_dev, grad, keep, 3, nlml_dev, grad_dev, status_dev, false, keep);
 }
 
 int medgp_nlml_grad(medgp_ctx *c, int nbatch, const int32_t *slots, const double *theta, int flag_grad, double *nlml,
@@ -1193,7 +1409,9 @@ int medgp_screen(medgp_ctx *c, int nslots, const int32_t *slots, int ninit, cons
     std::vector<int> perm(nslots);
     for (int s = 0; s < nslots; s++) perm[s] = s;
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return c->h_n[slots[a]] > c->h_n[slots[b]]; });
-    // chunks of consecutive (patient, init) entries: at most max_batch of them, and at most 48 GB of per-entry matrices
+    // chunks of consecutive (patient, init) entries (screen_chunk_end)
+    std::vector<int> walk_n(nslots);
+    for (int s = 0; s < nslots; s++) walk_n[s] = c->h_n[slots[perm[s]]];
     std::vector<int32_t> cs;
     std::vector<int> tp;
     size_t e0 = 0;
@@ -1201,22 +1419,11 @@ int medgp_screen(medgp_ctx *c, int nslots, const int32_t *slots, int ninit, cons
     c->tpos_on = true;
     while (e0 < total && rc == MEDGP_OK) {
         cs.clear(); tp.clear();
-        long long bytes = 0;
-        size_t e = e0;
-        while (e < total && (int)cs.size() < c->max_batch) {
-            const int s = perm[e / ninit], n = c->h_n[slots[s]];
-            const long long ld = (std::max(n, 1) + 63) / 64 * 64, per = 16 * ld * ld;
-            if (!cs.empty() && bytes + per > (48LL << 30)) break;
-            // Entries so large that 48 GB hold at most 144 of them take the look-ahead schedule anyway, whose throughput saturates at a
-            // few dozen entries: 32 per chunk then (N = 5832: 26 GB of matrices + scratch instead of 72 GB -- the FIRST use of device
-            // memory costs 0.1-0.2 s per GB on this platform: rocprofv3 --hip-trace of a 512-patient heavy-tailed run: hipMalloc 5.7 s)
-            if ((48LL << 30) / per <= 144 && (int)cs.size() >= 32) break;
-            cs.push_back(slots[s]); tp.push_back((int)(e % ninit));
-            bytes += per; e++;
-        }
+        const size_t e = screen_chunk_end(c, walk_n, ninit, e0, total);
+        for (size_t x = e0; x < e; x++) { cs.push_back(slots[perm[x / ninit]]); tp.push_back((int)(x % ninit)); }
         const int nb = (int)cs.size();
         int max_n = 0;
-        if ((rc = set_batch(c, nb, cs.data(), &max_n, false))) break;
+        if ((rc = set_batch(c, nb, cs.data(), &max_n, false, false))) break;
         {   // theta rows in the plan's internal order
             void *pin = nullptr;
             if ((rc = pin_stage(c, sizeof(int) * nb, &pin))) break;
@@ -1326,7 +1533,7 @@ int medgp_get_factor(medgp_ctx *c, int b, float *alpha, float *linv, float *beta
         const int nb1 = blocks64(n);
         const bool la1 = !c->use_v0 && !c->pin_route && nb1 >= 2 && (c->force_mc > 0 || (c->force_mc == 0 && nb1 >= 3));
         std::vector<LaNeed> las;
-        if (la1) { las.push_back({1, nb1, ld, LaArgs{}}); int rcl = ensure_la(c, las); if (rcl) return rcl; }
+        if (la1) { las.push_back({1, nb1, ld, LaArgs{}}); int rcl = ensure_la(c, las, true); if (rcl) return rcl; }
         const int route1 = la1 ? ROUTE_LA : (c->pin_route ? ROUTE_WG84 : (c->cholinv_nw ? (c->cholinv_nw == 44 ? ROUTE_WG44 : ROUTE_WG84) : (nb1 <= 4 ? ROUTE_WG44 : ROUTE_WG84)));
         int rc = run_pipeline_one(c, c->stream, V, 1, nb1, nullptr, 0, true, 1, nullptr, nullptr, nullptr, false, &n, route1, la1 ? &las[0].A : nullptr);
         c->profiling = prof;
@@ -1381,7 +1588,7 @@ static int fit_predict_impl(medgp_ctx *c, int nbatch, const int32_t *slots, cons
     int max_n = 0, rc;
     // patients are used in the caller's order when that differs from the grouped one?  No: mean / var are permutation
     // invariant, the grouped copy serves.
-    if ((rc = set_batch(c, nbatch, slots, &max_n, false))) return rc;
+    if ((rc = set_batch(c, nbatch, slots, &max_n, false, true))) return rc;   // (the diagonal blocks U_kk live in Linv)
     std::vector<double> ht2(ntot);
     std::vector<int> hm2(ntot, 0);
     for (int j = 0; j < ntot; j++) {
@@ -1395,7 +1602,7 @@ static int fit_predict_impl(medgp_ctx *c, int nbatch, const int32_t *slots, cons
     HIPCHK(c, hipMemcpyAsync(c->d_t2, ht2.data(), sizeof(double) * ntot, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_meta2, hm2.data(), sizeof(int) * ntot, hipMemcpyHostToDevice, c->stream));
     // factor + z = L^-1 y only (no inverse): k* rides along as one more right-hand side in k_predict
-    if ((rc = run_pipeline(c, nbatch, max_n, c->d_theta, 0, false, 1, nullptr, nullptr, nullptr, true))) return rc;
+    if ((rc = run_pipeline(c, nbatch, max_n, c->d_theta, 0, false, 1, nullptr, nullptr, nullptr, true, true))) return rc;
     for (const SizeClass &k : c->plan.cls) {   // (behind the join of the classes' chains: one launch per class view)
         Launcher l(c, KID_PREDICT);
         hipLaunchKernelGGL(k_predict, dim3(nstar, k.count), dim3(256), 0, c->stream, class_view(c, k), nstar, c->d_meta2, c->d_t2, c->d_ks, c->d_mean, c->d_var);
@@ -1417,9 +1624,9 @@ int medgp_factor_batch(medgp_ctx *c, int nbatch, const int32_t *slots, const dou
     if (c->max_slots == 0) return fail(c, MEDGP_ERR_CAPACITY, "call medgp_reserve first");
     HIPCHK(c, hipSetDevice(c->device));
     int max_n = 0, rc;
-    if ((rc = set_batch(c, nbatch, slots, &max_n, true))) return rc;       // the CALLER's observation order; size classes
+    if ((rc = set_batch(c, nbatch, slots, &max_n, true, false))) return rc;       // the CALLER's observation order; size classes; L and z only: no Linv
     HIPCHK(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * c->H * nbatch, hipMemcpyHostToDevice, c->stream));
-    if ((rc = run_pipeline(c, nbatch, max_n, c->d_theta, 0, false, 1, nullptr, nullptr, nullptr, false))) return rc;
+    if ((rc = run_pipeline(c, nbatch, max_n, c->d_theta, 0, false, 1, nullptr, nullptr, nullptr, false, true))) return rc;
     std::vector<int> st(nbatch, 0);
     {
         std::vector<int> sti(nbatch, 0);

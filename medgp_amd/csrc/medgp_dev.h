@@ -17,8 +17,12 @@
 
 #define MEDGP_MAX_D 256   // outputs per context (per-output offset tables are staged in LDS)
 
-struct MedgpPrior {          // one hyper of one slot
+struct MedgpPrior {          // one hyper of one slot (16 bytes)
     float p0, p1;
+    float lg2b;              // Laplace only: log(2 p1) AS THE REFERENCE EVALUATES IT -- `log(2*param[1])` with a float argument is
+                             // std::log(float) (ref: prior/c_prior.cpp:404, found by running the reference's compiled c_prior, round 6):
+                             // single precision, 5e-10 relative away from the fp64 value.  Filled on the host by the C library's logf
+                             // (medgp_set_prior[s]), so the device adds the very float the reference's libm produced.
     int8_t type;             // -1 none, 0 clamp, 1 normal, 2 laplace  (ref: prior/c_prior.h:50-53)
     uint8_t flag, is_exp, pad;
 };

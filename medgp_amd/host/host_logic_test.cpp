@@ -353,7 +353,82 @@ static int test_loader(const char *tmpdir) {
     return 0;
 }
 
+// The host's c_prior (medgp_host.cpp: the mirror of the reference's prior/c_prior.cpp the trainer and the tester build their
+// descriptors with) printed in the format of tests/golden/ref_prior.json.gz, which oracle/ref_prior_dump.cpp wrote from the
+// REFERENCE's own compiled c_prior: same cases, same keys (tests/test_ref_prior.py compares them entry by entry).
+static void pd_bools(const char *name, const std::vector<bool> &v) {
+    printf("\"%s\": [", name);
+    for (size_t i = 0; i < v.size(); i++) printf("%d%s", v[i] ? 1 : 0, i + 1 < v.size() ? "," : "");
+    printf("], ");
+}
+static void pd_ints(const char *name, const std::vector<int> &v, bool last = false) {
+    printf("\"%s\": [", name);
+    for (size_t i = 0; i < v.size(); i++) printf("%d%s", v[i], i + 1 < v.size() ? "," : "");
+    printf("]%s", last ? "" : ", ");
+}
+static void pd_dbls(const char *name, const std::vector<double> &v, bool last = false) {
+    printf("\"%s\": [", name);
+    for (size_t i = 0; i < v.size(); i++) printf("%.17g%s", v[i], i + 1 < v.size() ? "," : "");
+    printf("]%s", last ? "" : ", ");
+}
+static void pd_fix(const char *name, const std::vector<std::vector<float>> &v) {
+    std::vector<int> len;
+    std::vector<double> p0, p1;
+    for (const auto &e : v) { len.push_back((int)e.size()); p0.push_back(e.size() > 0 ? (double)e[0] : -1e30); p1.push_back(e.size() > 1 ? (double)e[1] : -1e30); }
+    char nm[64];
+    snprintf(nm, sizeof nm, "%s_len", name); pd_ints(nm, len);
+    snprintf(nm, sizeof nm, "%s_p0", name); pd_dbls(nm, p0);
+    snprintf(nm, sizeof nm, "%s_p1", name); pd_dbls(nm, p1);
+}
+static void pd_prior(const c_prior &p, const char *key, int ncov, bool last = false) {
+    printf("\"%s\": {", key);
+    pd_bools("flag_lik", p.flag_lik); pd_bools("flag_cov", p.flag_cov); pd_bools("flag_mean", p.flag_mean);
+    pd_bools("exp_lik", p.exp_lik); pd_bools("exp_cov", p.exp_cov); pd_bools("exp_mean", p.exp_mean);
+    pd_ints("type_lik", p.type_lik); pd_ints("type_cov", p.type_cov); pd_ints("type_mean", p.type_mean);
+    pd_fix("fix_lik", p.fix_param_lik); pd_fix("fix_cov", p.fix_param_cov); pd_fix("fix_mean", p.fix_param_mean);
+    pd_dbls("cov_varEM", p.get_cov_varEM_all());
+    std::vector<double> fx;
+    for (int i = 0; i < 5 && !p.get_cov_varEM_all().empty(); i++) fx.push_back(p.get_cov_varEM_fix_one(i));
+    pd_dbls("cov_varEM_fix", fx, true);
+    (void)ncov;
+    printf("}%s", last ? "" : ", ");
+}
+static int prior_dump() {
+    std::cout.rdbuf(std::cerr.rdbuf());   // (c_prior prints the reference's progress lines on cout)
+    const int shapes[3][3] = {{5, 2, 2}, {5, 24, 8}, {5, 64, 8}};
+    const float eta = 0.01f, beta_lam = 0.01f;
+    printf("{\"shapes\": [");
+    for (int s = 0; s < 3; s++) {
+        const int Q = shapes[s][0], D = shapes[s][1], R = shapes[s][2], ncov = Q * (D * R + 2 + D), nlik = D;
+        const std::vector<int> kp = {Q, D, R};
+        const std::vector<float> pp = {eta, beta_lam};
+        printf("{\"Q\": %d, \"D\": %d, \"R\": %d, ", Q, D, R);
+        c_prior p0(ncov, 0, nlik); p0.setup_param(7, kp, 0, pp); pd_prior(p0, "mode0", ncov);
+        c_prior p2(ncov, 0, nlik); p2.setup_param(7, kp, 2, pp); pd_prior(p2, "mode2", ncov);
+        c_prior pd(ncov, 0, nlik); pd.setup_param(7, kp, 2, std::vector<float>()); pd_prior(pd, "mode2_default", ncov);
+        c_prior pk(3, 0, 1); pk.setup_param(0, kp, 2, pp); pd_prior(pk, "mode2_kernel0", 3);
+        std::vector<double> mode((size_t)(nlik + ncov));
+        for (size_t i = 0; i < mode.size(); i++) mode[i] = 0.125 * (double)((int)(i % 7) - 3);
+        c_prior pt(ncov, 0, nlik); pt.setup_param(7, kp, 2, pp); pt.init_test_prior(7, kp, mode); pd_prior(pt, "mode2_test", ncov);
+        c_prior pt0(ncov, 0, nlik); pt0.setup_param(7, kp, 0, pp); pt0.init_test_prior(7, kp, mode); pd_prior(pt0, "mode0_test", ncov);
+        std::vector<int> gf, gt;
+        for (int i = 0; i < nlik + ncov; i++) { gf.push_back(pt.get_one_prior_flag(i) ? 1 : 0); gt.push_back(pt.get_one_prior_type(i)); }
+        pd_ints("test_flag_theta_order", gf);
+        pd_ints("test_type_theta_order", gt);
+        // the flat theta-order arrays medgp_set_prior receives
+        std::vector<uint8_t> f, e; std::vector<int32_t> t; std::vector<float> a, b;
+        pt.flatten(f, t, e, a, b);
+        std::vector<int> fi(f.begin(), f.end()), ei(e.begin(), e.end()), ti(t.begin(), t.end());
+        std::vector<double> ad(a.begin(), a.end()), bd(b.begin(), b.end());
+        pd_ints("flat_flag", fi); pd_ints("flat_type", ti); pd_ints("flat_exp", ei); pd_dbls("flat_p0", ad); pd_dbls("flat_p1", bd, true);
+        printf("}%s", s < 2 ? ", " : "");
+    }
+    printf("]}\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 2 && !strcmp(argv[1], "priordump")) return prior_dump();
     if (argc >= 3 && !strcmp(argv[1], "loader")) return test_loader(argv[2]);
     if (argc >= 2 && !strcmp(argv[1], "scg")) return test_scg();
     if (argc >= 2 && !strcmp(argv[1], "pool")) return test_pool();

@@ -108,7 +108,7 @@ int header_count(const c_experiment &ex, const string &PAN) {
 
 static int train_main(int argc, const char *argv[]) {
     string exp_cfg, pan_arg, pan_list, queue_file, order_arg = "size";
-    int thread_num = 1, device = 0, max_batch = 1024, host_threads = 0, pingpong_min = 512, merge_below = 256, resident = 1024, admit_min = -1, max_n_arg = 0;
+    int thread_num = 1, device = 0, max_batch = 1024, host_threads = 0, pingpong_min = 512, merge_below = 256, resident = 1024, admit_min = -1, max_n_arg = 0, share = 1;
     bool pin_route = false;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--cfg") && i + 1 < argc) exp_cfg = argv[++i];
@@ -125,6 +125,7 @@ static int train_main(int argc, const char *argv[]) {
         else if (!strcmp(argv[i], "--queue") && i + 1 < argc) queue_file = argv[++i];                  // shared work counter: several trainers walk ONE list
         else if (!strcmp(argv[i], "--order") && i + 1 < argc) order_arg = argv[++i];                   // size (longest first, default) | list
         else if (!strcmp(argv[i], "--max-n") && i + 1 < argc) max_n_arg = atoi(argv[++i]);             // largest observation count of the list (skips the header scan)
+        else if (!strcmp(argv[i], "--share") && i + 1 < argc) share = std::max(1, atoi(argv[++i]));   // trainers that walk the --queue list together: bounds this trainer's first read-ahead to its share
         else if (!strcmp(argv[i], "--pin-route")) pin_route = true;   // medgp_pin_route: bit-identical results whatever the batch (slower for few large patients)
         else { cout << "Error: unknown argument: " << argv[i] << endl; return 1; }
     }
@@ -220,7 +221,10 @@ static int train_main(int argc, const char *argv[]) {
         p->load_log = os.str();
         return p;
     };
-    ReadAhead<Patient> loader(order.size(), tickets, (size_t)resident, std::max(1, host_threads), load_patient);
+    // first fill: the whole resident set -- but with a shared counter at most this trainer's share of the list, so that the split
+    // between the GPUs is decided by load, not by which rank's readers reached the file system first (--share from train_cohort.py)
+    const size_t first_cap = queue_file.empty() ? (size_t)resident : std::min<size_t>((size_t)resident, (pans.size() + (size_t)share - 1) / (size_t)share);
+    ReadAhead<Patient> loader(order.size(), tickets, std::max<size_t>(first_cap, 1), std::max(1, host_threads), load_patient);
     bool filled = false;
 
     vector<vector<double>> global_hyp_array;
@@ -253,7 +257,7 @@ static int train_main(int argc, const char *argv[]) {
         n_finished++;
     };
 
-    long long total_evals = 0, steps = 0, screen_evals = 0, admissions = 0;
+    long long total_evals = 0, steps = 0, screen_evals = 0, admissions = 0, n_unreadable = 0;
     double t_wait = 0.0, t_host = 0.0, t_screen = 0.0, t_admit = 0.0;   // seconds blocked in medgp_wait / in the optimiser state machines / in the screening calls / in admissions as a whole
     vector<std::unique_ptr<Patient>> owned;   // every patient currently resident (or being admitted)
 
@@ -265,8 +269,15 @@ static int train_main(int argc, const char *argv[]) {
         for (auto &up : in) {
             Patient *p = up.get();
             cout << p->load_log;
-            if (!p->load_err.empty()) { cout << "ERROR: " << p->load_err << endl; return false; }
-            if ((int)p->t.size() > max_n) { cout << "ERROR: patient " << p->PAN << " has " << p->t.size() << " observations, more than the " << max_n << " the list announced" << endl; return false; }
+            // A patient that cannot be read, or is larger than the list announced, is skipped like one with too few samples: flag 0
+            // through finish(), the run goes on, the exit status is non-zero at the end (the reference's one-process-per-patient model
+            // loses exactly that patient too; medgp_test does the same, n_unreadable).  Round 5 ended the whole trainer here, dropping
+            // every resident patient's progress and the tickets it had already pulled from a shared queue.
+            if (!p->load_err.empty()) { cout << "ERROR: " << p->load_err << " -- patient " << p->PAN << " skipped" << endl; p->sample_flag = false; n_unreadable++; }
+            else if ((int)p->t.size() > max_n) {
+                cout << "ERROR: patient " << p->PAN << " has " << p->t.size() << " observations, more than the " << max_n << " the list announced -- skipped" << endl;
+                p->sample_flag = false; n_unreadable++;
+            }
             owned.push_back(std::move(up));
             if (!p->sample_flag) { finish(*p); continue; }
             p->slot = free_slots.back(); free_slots.pop_back();
@@ -355,6 +366,20 @@ static int train_main(int argc, const char *argv[]) {
     G = std::max(G, 1);
     const size_t gcap = ((size_t)resident + G - 1) / G;            // members a group is filled up to
     const size_t bufcap = std::min<size_t>((size_t)resident, std::max<size_t>((size_t)max_batch, gcap));   // (a merged group may hold everybody that is left)
+    // ---------------- the device's per-entry arenas, sized ONCE (round 6): the largest lock-step call is a group of the gcap largest
+    // patients of the list (it is walked longest first; a merged tail group holds fewer and smaller ones), the largest screening chunks
+    // are theirs too -- medgp_reserve_plan lays both out on the sizes alone and maps that much.  Obtaining device memory can take seconds
+    // on this platform when an earlier process has used it (medgp_hip.h); that wait now happens here, not inside the loop.
+    double t_plan = 0.0;
+    {
+        vector<int32_t> top;
+        vector<int> by_size(nhint);
+        std::sort(by_size.begin(), by_size.end(), [](int a, int b) { return a > b; });
+        for (size_t i = 0; i < by_size.size() && i < gcap; i++) top.push_back(std::max(0, by_size[i]));
+        const auto tp0 = now();
+        if (!top.empty() && medgp_reserve_plan(ctx, (int)top.size(), top.data(), ninit)) { cout << "ERROR: " << medgp_last_error(ctx) << endl; return 1; }
+        t_plan = secs(tp0, now());
+    }
     vector<Group> groups((size_t)G);
     for (Group &g : groups) {
         g.cap = gcap;
@@ -521,11 +546,18 @@ static int train_main(int argc, const char *argv[]) {
     owned.clear();
     const bool counter_failed = loader.failed();
     if (counter_failed) cout << "ERROR: the work counter " << queue_file << " could not be read or updated; patients of the list may be untrained" << endl;
+    {   // where the host waited for device memory instead of queueing work (medgp_alloc_stats)
+        double as = 0.0; int64_t an = 0, ab = 0;
+        if (medgp_alloc_stats(ctx, &as, &an, &ab) == 0)
+            cout << "INFO: device memory: " << as << " s in " << an << " management calls (" << t_plan << " s of it announcing the sizes up front), "
+                 << (double)ab / 1073741824.0 << " GB mapped into the per-entry arenas" << endl;
+    }
+    if (n_unreadable) cout << "ERROR: " << n_unreadable << " patient(s) could not be read or exceeded the announced size; they were skipped (flag 0)" << endl;
     if (ctx) medgp_destroy(ctx);
     time_t t_end;
     time(&t_end);
     cout << "Finish all jobs. Total elapsed time = " << difftime(t_end, t_start) << " seconds" << endl;
-    return counter_failed ? 1 : 0;
+    return (counter_failed || n_unreadable) ? 1 : 0;
 }
 
 // exceptions of the host side (bad_alloc, a throwing loader on a worker thread: WorkPool rethrows them on the calling thread)

@@ -12,7 +12,7 @@ so cost = sum over observations of N_tt^3, plus n^3 for the one shared factorisa
 The only collective is the agreement on the exit status (all_reduce MAX): every rank returns non-zero if any shard failed.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
-        -m medgp_amd.test_cohort --cfg exp_setup.json --pan-list pans.txt --fold 0 --kernclust-alg gmm
+        -m medgp_amd.impute_cohort --cfg exp_setup.json --pan-list pans.txt --fold 0 --kernclust-alg gmm
 """
 import argparse
 import json
@@ -42,7 +42,7 @@ def read_times(cfg, pan):
     return np.concatenate(ts) if ts else np.zeros(0, np.float32)
 
 
-def test_cost(t, window=72.0):
+def impute_cost(t, window=72.0):
     """sum_i N_i^3 + n^3: N_i = observations strictly before t_i within the window + the other observations at t_i."""
     t = np.sort(np.asarray(t, dtype=np.float64))
     n = t.size
@@ -92,7 +92,7 @@ def main(argv=None):
 
     cfg = json.load(open(args.cfg))
     pans = [p for p in open(args.pan_list).read().split() if p]
-    costs = [test_cost(read_times(cfg, p)) for p in pans]
+    costs = [impute_cost(read_times(cfg, p)) for p in pans]
     parts = lpt(costs, world)
     mine = [pans[i] for i in parts[rank]]
     rc = 0

@@ -143,7 +143,7 @@ def main(argv=None):
             sys.exit("train_cohort: --schedule dynamic shares one counter file between the ranks of ONE node; use --schedule static across nodes")
         qfile = queue_path(cfg["exp_train_dir"])
         t0 = time.perf_counter()
-        rc, mine = run_trainer(list(range(len(pans))), f"queue_rank{rank}", ["--queue", qfile])
+        rc, mine = run_trainer(list(range(len(pans))), f"queue_rank{rank}", ["--queue", qfile, "--share", str(world)])
         t_busy = time.perf_counter() - t0
     mine = sorted(set(mine))
     with open(os.path.join(cfg["exp_train_dir"], f"train_rank{rank}.busy"), "w") as f:

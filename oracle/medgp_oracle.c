@@ -27,10 +27,16 @@
  * the first non-positive or NaN pivot; trti2; forward/back substitution).
  *
  * PARITY PINNING STATUS -- "partially pinned":
- *   The reference has no tests, golden vectors or fixtures, and its C++ path is
- *   UNBUILDABLE here under the round's rules: it needs <mkl.h> (Intel MKL development headers) and
- *   rapidjson, neither of which is on the image, and writing stand-ins for them is not allowed.
- *   What pins this oracle instead:
+ *   The reference has no tests, golden vectors or fixtures, and the C++ files of its HOT PATH are
+ *   UNBUILDABLE here under the round's rules: every one includes <mkl.h> (Intel MKL development headers) or
+ *   rapidjson, neither of which is on the image, and writing stand-ins for them is not allowed.  Three translation
+ *   units of the reference DO compile unmodified with plain g++ -- prior/c_prior.cpp, core/c_hyperparam.cpp and
+ *   inference/c_inference_prior.cpp -- and since round 6 they are built (`make -C oracle ref`) and pin item (0) below.
+ *   What pins this oracle:
+ *     (0) the reference's own compiled c_prior / c_hyperparam / c_inference_prior: prior descriptors after setup_param
+ *         and init_test_prior, the variational-EM start state, prior_lik_normal / prior_lik_laplace on a grid, the
+ *         theta split, and -- with the dense evaluation handed in by the driver -- the prior stage's nlml shift,
+ *         chain rule and clamp (tests/golden/ref_prior*.json.gz, tests/test_ref_prior.py);
  *     (1) the reference's own Python statement of B_q and k_q (medgpc/visualization/fastkernel.py:13-48),
  *         imported in the build container to generate tests/golden/fastkernel_*.npz;
  *     (2) the reference-run known answers recorded in SURVEY.md section 8c / Appendix A (nlml of the
@@ -251,7 +257,10 @@ static void prior_normal(double x, float p0, float p1, double pi, double *lp, do
     *dlp = -1.0 * (x - p0) / p1;
 }
 static void prior_laplace(double x, float p0, float p1, double *lp, double *dlp) {
-    *lp = (-1.0 * fabs(x - p0) / p1) - log(2 * p1);
+    /* `log(2*param[1])`: the argument is a float, and in the reference's C++ (<math.h> + using namespace std) that call is
+     * std::log(float) -- SINGLE precision.  Found by holding this function to the reference's compiled c_prior (round 6,
+     * tests/test_ref_prior.py): the fp64 log restated here in rounds 1-5 was 5e-10 relative away. */
+    *lp = (-1.0 * fabs(x - p0) / p1) - (double)logf(2.0f * p1);
     if (x == p0) *dlp = 0.0;
     else *dlp = -1.0 * ((x > p0) ? 1.0 : -1.0) / p1;
 }
@@ -271,6 +280,18 @@ static void apply_prior(int H, const double *hval, double pi, int flag_grad,
         *nlml -= lp;
         if (flag_grad) grad[i] -= (pexp && pexp[i]) ? hval[i] * dlp : dlp;
     }
+}
+
+/* the two functions above on their own, for the tests that hold them to the REFERENCE's compiled c_prior / c_inference_prior
+ * (tests/golden/ref_prior*.json.gz, written by oracle/ref_prior_dump.cpp and ref_prior_inference_dump.cpp) */
+void medgp_oracle_prior_lik(int type, double x, float p0, float p1, double pi, double *lp, double *dlp) {
+    *lp = 0.0; *dlp = 0.0;
+    if (type == 1) prior_normal(x, p0, p1, pi, lp, dlp);
+    else if (type == 2) prior_laplace(x, p0, p1, lp, dlp);
+}
+void medgp_oracle_apply_prior(int H, const double *hval, double pi, int flag_grad, const uint8_t *pflag, const int32_t *ptype,
+                              const uint8_t *pexp, const float *p0, const float *p1, double *nlml, double *grad) {
+    apply_prior(H, hval, pi, flag_grad, pflag, ptype, pexp, p0, p1, nlml, grad);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -54,6 +54,13 @@ int medgp_oracle_gram(int kernel_index, int Q, int D, int R, double pi,
                       int n, const int32_t *meta, const float *t,
                       const double *theta, double *K);
 
+/* prior log-densities and the prior stage on their own (ref: prior/c_prior.cpp:383-421, inference/c_inference_prior.cpp:60-150):
+ * type 1 normal (p0 mean, p1 variance), 2 laplace (p0 location, p1 scale), anything else: lp = dlp = 0.
+ * apply_prior: hval[H] = transformed hyper values in theta order, nlml / grad updated in place (grad may be NULL when !flag_grad). */
+void medgp_oracle_prior_lik(int type, double x, float p0, float p1, double pi, double *lp, double *dlp);
+void medgp_oracle_apply_prior(int H, const double *hval, double pi, int flag_grad, const uint8_t *pflag, const int32_t *ptype,
+                              const uint8_t *pexp, const float *p0, const float *p1, double *nlml, double *grad);
+
 /* The operator: c_inference_prior::compute_nlml restated in fp64.
  *   prior_* arrays have one entry per hyper in theta order (may all be NULL = no prior):
  *     prior_flag  : 1 = prior active for this hyper            (ref: prior/c_prior.h:35-38)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# stand-in for medgp_test in the CPU test of medgp_amd.test_cohort: writes the flag file of both passes per patient of the shard
+# stand-in for medgp_test in the CPU test of medgp_amd.impute_cohort: writes the flag file of both passes per patient of the shard
 # usage: ... --cfg CFG --pan-list FILE --fold K --kernclust-alg ALG --device D
 while [ $# -gt 0 ]; do case "$1" in --cfg) CFG=$2; shift 2;; --pan-list) PL=$2; shift 2;; --fold) FOLD=$2; shift 2;; *) shift;; esac; done
 python3 - "$CFG" "$PL" "$FOLD" <<'PY'

@@ -8,6 +8,8 @@ it reads /root/reference, which does not exist on the GPU box).
    distributions on mt19937(1234)) together with the nlml the COMPILED REFERENCE printed for them, as
    recorded in SURVEY.md section 8c (the reference cannot be rebuilt under this round's rules: it needs
    <mkl.h> and rapidjson), plus the oracle's own fp64 outputs for regression.
+3. ref_prior*.json   -- outputs of the part of the reference's C++ that DOES compile here unmodified (c_prior, c_hyperparam,
+   c_inference_prior), see ref_prior() below (round 6).
 """
 import os
 import subprocess
@@ -238,7 +240,24 @@ def ref_feature_roundtrip():
         os.chdir(cwd)
 
 
+def ref_prior():
+    """tests/golden/ref_prior.json.gz, ref_prior_inference.json.gz: outputs of the reference's OWN compiled code -- the three translation
+    units of /root/reference/medgpc/src that build unmodified with plain g++ (prior/c_prior.cpp, core/c_hyperparam.cpp,
+    inference/c_inference_prior.cpp; no MKL, no rapidjson, no stand-in headers), built by `make -C oracle ref` into oracle/_ref/ and
+    driven by oracle/ref_prior_dump.cpp and oracle/ref_prior_inference_dump.cpp (whose headers say exactly what is and is not the
+    reference in each).  Pins rows a2 (theta split), a19 (prior terms) and the variational-EM start state of f1."""
+    import json
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL)
+    for exe, name in (("ref_prior_dump", "ref_prior.json"), ("ref_prior_inference_dump", "ref_prior_inference.json")):
+        txt = subprocess.run([os.path.join(ROOT, "oracle", "_ref", exe)], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
+        d = json.loads(txt)            # (must parse)
+        import gzip
+        with gzip.GzipFile(os.path.join(HERE, name + ".gz"), "wb", mtime=0) as f:    # (mtime 0: the same bytes on every run)
+            f.write(txt.encode())
+        print(name + ".gz", len(txt), "bytes of JSON;", list(d.keys()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["appendix_a", "fastkernel", "fastkernel_gram", "fastkernel_univariate", "config5", "ref_config_files", "ref_feature_roundtrip"]
+    which = sys.argv[1:] or ["appendix_a", "fastkernel", "fastkernel_gram", "fastkernel_univariate", "config5", "ref_config_files", "ref_feature_roundtrip", "ref_prior"]
     for w in which:
         globals()[w]()

@@ -24,10 +24,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, extra, dump):
+def _run(world, extra, dump, self_launch=False):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if world == 1:
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"]
+    if world == 1 or self_launch:   # self_launch (round 6): `python bench.py --gpus N` with no launcher starts its N ranks itself
+        env = {k: v for k, v in env.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world)]
@@ -44,11 +45,12 @@ def _run(world, extra, dump):
     return json.loads(lines[0]), res
 
 
-@pytest.mark.parametrize("mode", ["weak", "strong"])
+@pytest.mark.parametrize("mode", ["weak", "strong", "weak-self-launch"])
 def test_two_ranks_on_one_gpu_match_one_rank(tmp_path, mode):
-    if mode == "weak":
+    if mode.startswith("weak"):
         one, r1 = _run(1, ["--patients", "48"], str(tmp_path / "one"))
-        two, r2 = _run(2, ["--patients", "24"], str(tmp_path / "two"))
+        two, r2 = _run(2, ["--patients", "24"], str(tmp_path / "two"), self_launch=mode.endswith("self-launch"))
+        mode = "weak"
     else:
         one, r1 = _run(1, ["--scaling", "strong", "--cohort", "50"], str(tmp_path / "one"))
         two, r2 = _run(2, ["--scaling", "strong", "--cohort", "50"], str(tmp_path / "two"))
@@ -105,3 +107,15 @@ def test_one_rank_under_torchrun_runs_the_rccl_path(tmp_path):
     d = np.load(f"{dump}.rank0.npz")
     for g, nl, gs, st in zip(d["gids"], d["nlml"], d["gsum"], d["status"]):
         assert r0[int(g)] == (nl, gs, int(st))
+
+
+def test_gpus_flag_must_match_the_launcher(tmp_path):
+    """`--gpus 1` (or none: the default) under a two-rank launcher: exit status 2 and NO line -- a run can no longer report
+    n_gpus != --gpus (round 5 parsed the flag and never read it)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--patients", "8"] + COMMON
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "refusing to print a line" in r.stderr

@@ -1,5 +1,5 @@
 """GPU tests of the cohort launchers with the REAL hosts: medgp_amd.train_cohort (static shards vs the shared patient queue) and
-medgp_amd.test_cohort under torch.distributed.run with two gloo ranks that share the one GPU of the test box.  Patients are
+medgp_amd.impute_cohort under torch.distributed.run with two gloo ranks that share the one GPU of the test box.  Patients are
 independent (ref: medgpc/util/run_exp_generator.py:213-260 fans them out as scheduler jobs), so whichever rank and chunk
 handles a patient, its files must be the same bytes as a single-process run."""
 import os
@@ -71,7 +71,7 @@ def test_train_and_test_cohort_launchers_two_ranks_one_gpu(tmp_path, built_lib):
     assert r.returncode == 0, r.stdout[-2000:]
     want = _files(exs["single"]["dirs"]["test"], "test_mean_")
     assert len(want) == 6 * 2 * 6
-    _launch("medgp_amd.test_cohort", ["--cfg", exs["static"]["cfg"], "--pan-list", str(plist), "--fold", "0", "--kernclust-alg", "gmm", "--backend", "gloo"], 29565)
+    _launch("medgp_amd.impute_cohort", ["--cfg", exs["static"]["cfg"], "--pan-list", str(plist), "--fold", "0", "--kernclust-alg", "gmm", "--backend", "gloo"], 29565)
     got = _files(exs["static"]["dirs"]["test"], "test_mean_")
     assert sorted(got) == sorted(want)
     for f in want:
@@ -110,7 +110,7 @@ def test_rccl_branches_with_one_rank(tmp_path, built_lib):
     os.makedirs(fold_dir)
     open(os.path.join(fold_dir, "gmm_mode_mixture_num.txt"), "w").write(f"{Q}\n")
     np.fromfile(os.path.join(ex["dirs"]["train"], "train_hyp_P001.bin"), np.float64).tofile(os.path.join(fold_dir, "gmm_mode_param.bin"))
-    launch(["-m", "medgp_amd.test_cohort", "--cfg", ex["cfg"], "--pan-list", str(plist), "--fold", "0", "--kernclust-alg", "gmm", "--backend", "nccl"], 29573)
+    launch(["-m", "medgp_amd.impute_cohort", "--cfg", ex["cfg"], "--pan-list", str(plist), "--fold", "0", "--kernclust-alg", "gmm", "--backend", "nccl"], 29573)
     assert open(os.path.join(ex["dirs"]["test"], "test_mean_w_update_flag_P002.txt")).read() == "1\n"
     r = launch([os.path.join(ROOT, "tests", "rccl_cohort_mode_worker.py")], 29575)
     assert "RCCL_COHORT_MODE_OK" in r.stdout

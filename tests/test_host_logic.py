@@ -127,27 +127,27 @@ def test_train_cohort_dynamic_queue_balances_skewed_budgets_over_gloo(tmp_path):
 
 
 def test_test_cohort_launcher_cost_model_and_gloo_run(tmp_path):
-    """medgp_amd.test_cohort: cost model = sum N_tt^3 over the 72-h windows + n^3; LPT shards over 2 gloo ranks with a stand-in
+    """medgp_amd.impute_cohort: cost model = sum N_tt^3 over the 72-h windows + n^3; LPT shards over 2 gloo ranks with a stand-in
     tester; a failing shard makes every rank return non-zero."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from exp_fixture import make_experiment
-    from medgp_amd import test_cohort
+    from medgp_amd import impute_cohort
     # three observations at t = 0, 1, 1 and one at t = 100: N_i = 0, 2, 2 (before + same time), 0 (window) -> 16 + 4^3
-    assert test_cohort.test_cost(np.array([0.0, 1.0, 1.0, 100.0])) == 16.0 + 64.0
-    assert test_cohort.test_cost(np.zeros(0)) == 0.0
-    assert test_cohort.lpt([5.0, 1.0, 4.0, 1.0], 2) == [[0, 3], [1, 2]]
+    assert impute_cohort.impute_cost(np.array([0.0, 1.0, 1.0, 100.0])) == 16.0 + 64.0
+    assert impute_cohort.impute_cost(np.zeros(0)) == 0.0
+    assert impute_cohort.lpt([5.0, 1.0, 4.0, 1.0], 2) == [[0, 3], [1, 2]]
     pans = [f"T{k:02d}" for k in range(5)]
     ex = make_experiment(tmp_path, pans, D=2, Q=2, R=2, N=[20, 44, 24, 40, 30])
     import json
     cfg = json.load(open(ex["cfg"]))
-    assert test_cohort.read_times(cfg, "T01").size == 44
+    assert impute_cohort.read_times(cfg, "T01").size == 44
     for names, want_rc in ((pans, 0), (pans[:4] + ["FAIL"], 3)):
         plist = tmp_path / "tpans.txt"
         plist.write_text("\n".join(names) + "\n")
         if "FAIL" in names:
             os.makedirs(os.path.join(ex["dirs"]["data"], "FAIL"), exist_ok=True)
         out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                              "--master-addr", "127.0.0.1", "--master-port", "29557", "-m", "medgp_amd.test_cohort",
+                              "--master-addr", "127.0.0.1", "--master-port", "29557", "-m", "medgp_amd.impute_cohort",
                               "--cfg", ex["cfg"], "--pan-list", str(plist), "--fold", "0", "--kernclust-alg", "gmm", "--backend", "gloo",
                               "--exe", os.path.join(ROOT, "tests", "gloo_test_cohort_worker.sh")],
                              env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -182,3 +182,46 @@ def test_exit_status_of_a_signalled_child_is_positive():
     assert shard.exit_status(0) == 0 and shard.exit_status(3) == 3
     assert shard.exit_status(-9) == 137 and shard.exit_status(-6) == 134      # SIGKILL, SIGABRT: the shell's 128 + s
     assert max(0, shard.exit_status(-11)) > 0
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_gpus_flag_means_something(capsys):
+    """bench.resolve_launch: --gpus N must equal the launcher's WORLD_SIZE (exit 2, no line), and without a launcher N > 1 starts the
+    N ranks itself through torch.distributed.run on 127.0.0.1 and leaves with that launch's exit code."""
+    bench = _load_bench()
+    env = {"RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29500"}
+    assert bench.resolve_launch(2, env, []) is None                       # launcher and flag agree: go on in this process
+    assert bench.resolve_launch(8, env, []) == 2                          # mismatch: refuse
+    assert "refusing to print a line" in capsys.readouterr().err
+    assert bench.resolve_launch(1, dict(env, WORLD_SIZE="2", RANK="1"), []) == 2
+    assert capsys.readouterr().err == ""                                  # (only rank 0 speaks)
+    assert bench.resolve_launch(1, {}, []) is None                        # plain `python bench.py`
+    seen = []
+    rc = bench.resolve_launch(4, {}, ["--gpus", "4", "--steps", "3"], run=lambda cmd: (seen.append(cmd), 7)[1])
+    assert rc == 7
+    cmd = seen[0]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and os.path.basename(cmd[-5]) == "bench.py"
+
+
+def test_bench_gpus_2_without_a_launcher_never_prints_an_n_gpus_1_line():
+    """`python bench.py --gpus 2` with no launcher environment (here: no GPU either, so the ranks fail): whatever happens, no JSON line
+    with n_gpus != 2 comes out and the exit status is not 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extra", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert all(ln["n_gpus"] == 2 for ln in lines)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and not lines
+    assert "starting 2 ranks" in r.stderr

@@ -180,7 +180,9 @@ def test_oracle_prior_terms():
     A = th[D:D + Q * D * R]
     kap = np.exp(th[D + Q * (D * R + 2):])
     b = np.float64(np.float32(0.01))
-    lp = np.sum(-A[1:] ** 2 / 2 - np.log(2 * O.REF_PI) / 2) + np.sum(-kap / b - np.log(2 * b))
+    # (the Laplace normaliser is log(2 b) in SINGLE precision, as the reference's `log(2*param[1])` with a float argument evaluates
+    #  it, ref: prior/c_prior.cpp:404 -- pinned to the compiled reference in tests/test_ref_prior.py)
+    lp = np.sum(-A[1:] ** 2 / 2 - np.log(2 * O.REF_PI) / 2) + np.sum(-kap / b - np.float64(np.log(np.float32(2) * np.float32(0.01))))
     assert abs((base["nlml"] - lp) - r["nlml"]) < 1e-9 * abs(r["nlml"])
     assert r["grad"][D] == 0.0
     np.testing.assert_allclose(r["grad"][D + 1:D + Q * D * R], base["grad"][D + 1:D + Q * D * R] + A[1:], rtol=1e-12)

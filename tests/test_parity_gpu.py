@@ -371,3 +371,52 @@ def test_batch_shapes_of_the_kernel_variants(P, N, force_single, monkeypatch):
         m, t, y = pts[p]
         assert_parity(nlml[p], grad[p], O.nlml_grad(7, Q, D, R, m, t, y, th[p], nthreads=4), f"p{p}")
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["PT_INR_mode2", "PT_INR_mode2_varem", "PT_INR_mode2_testclamp", "PT_INR_mode0_testclamp",
+                                  "all24_mode2_varem", "all24_mode2_testclamp", "D64_mode2_varem"])
+def test_device_prior_stage_vs_reference_compiled_prior(case):
+    """k_epilogue's prior stage (row a19) against numbers the REFERENCE's own compiled code produced (round 6):
+    inference/c_inference_prior.cpp + prior/c_prior.cpp build unmodified with plain g++; oracle/ref_prior_inference_dump.cpp ran
+    c_inference_prior::compute_nlml on prior objects built by the reference's setup_param / init_test_prior / the variational-EM
+    writes and recorded, per hyper, what it did to a base (nlml, gradient): tests/golden/ref_prior_inference.json.gz.  The prior stage is
+    additive, so on the device (with prior) - (without prior) at the fixture's theta must be the reference's shift: nlml by - sum lp,
+    gradients by - hyp dlp (exp chain rule) or - dlp, clamped entries exactly 0 -- including the reference's SINGLE-precision
+    log(2 b) in the Laplace normaliser (ref: prior/c_prior.cpp:404), which only this comparison could find."""
+    import gzip
+    import json
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_prior_inference.json.gz"), "rt") as f:
+        c = next(x for x in json.load(f)["cases"] if x["name"] == case)
+    Q, D, R = c["Q"], c["D"], c["R"]
+    H = len(c["theta"])
+    th = np.array(c["theta"])[None, :]
+    flag = np.array(c["prior_flag"], np.uint8)
+    typ = np.array(c["prior_type"], np.int32)
+    ex = np.array(c["prior_exp"], np.uint8)
+    p0 = np.array(c["prior_p0"], np.float32)
+    p1 = np.array(c["prior_p1"], np.float32)
+    N = 3 * D + 40
+    m, t, y = synth.patient(77, 0, D, N)
+    ctx = medgp_amd.Context(7, Q, D, R)
+    assert ctx.H == H
+    ctx.reserve(1, N, 1)
+    ctx.set_patient(0, m, t, y)
+    n0, g0, s0 = ctx.nlml_grad([0], th, True)
+    ctx.set_prior(0, flag, typ, ex, p0, p1)
+    n1, g1, s1 = ctx.nlml_grad([0], th, True)
+    n1b, _, _ = ctx.nlml_grad([0], th, False)
+    ctx.close()
+    assert s0[0] == 0 and s1[0] == 0
+    ref_dn = c["nlml"] - c["base_nlml"]                      # = - sum of the reference's lp
+    ref_dg = np.array(c["dnlml"]) - np.array(c["base_dnlml"])
+    assert abs((n1[0] - n0[0]) - ref_dn) <= 1e-10 * max(abs(n1[0]), abs(ref_dn), 1.0), (n1[0] - n0[0], ref_dn)
+    assert abs(n1b[0] - n1[0]) <= 1e-12 * abs(n1[0])
+    clamp = (flag == 1) & (typ == 0)
+    assert (g1[0][clamp] == 0.0).all() and (np.array(c["dnlml"])[clamp] == 0.0).all()
+    free = ~clamp
+    err = np.abs((g1[0] - g0[0])[free] - ref_dg[free])
+    assert np.all(err <= 1e-10 * np.maximum(1.0, np.abs(g1[0][free]))), float(err.max())
+    if "mode2" in case:
+        assert np.any(ref_dg[free] != 0.0) and ref_dn != 0.0
+    else:
+        assert ref_dn == 0.0 and not np.any(ref_dg[free] != 0.0)     # mode 0: only the test-time clamp acts
