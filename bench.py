@@ -455,6 +455,28 @@ def host_paths(out, dev_index, seed):
             "patients": P3, "n_median": int(np.median(ns3)), "n_max": int(max(ns3)), "D": D, "random_init_num": 1000, "top_iteration_num": 40,
             "iteration_num_per_update": 30, **first, "repeat": second,
             "repeat_wall_ratio": second["process_wall_s"] / first["process_wall_s"]}
+        # ---- BASELINE config 1 as SURVEY 8d defines it: the REFERENCE-WRITTEN exp_setup.json / hyp_bound.txt / mode kernel (D = 2, Q = 5,
+        #      R = 2, H = 42, 1000 + 5 x 100 + 35 x 30), one patient of 75 + 75 observations, medgp_train then medgp_test (both passes);
+        #      parity of exactly this run: tests/test_config1_gpu.py
+        from medgp_amd.synth_experiment import reference_config1_tree
+        cwd1, cfg1, _, _, _ = reference_config1_tree(os.path.join(tmp, "config1"), os.path.dirname(os.path.abspath(__file__)))
+        t0 = time.perf_counter()
+        r = subprocess.run([os.path.join(host, "medgp_train"), "--cfg", cfg1, "--pan", "PT0001", "--thread", "1", "--device", str(dev_index)],
+                           capture_output=True, text=True, timeout=600, cwd=cwd1)
+        wall_tr = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError("medgp_train (config 1) rc %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:]))
+        m1 = re.search(r"optimization finished: (\d+) nlml\+grad evaluations in (\d+) lock-step batches", r.stdout)
+        t0 = time.perf_counter()
+        r = subprocess.run([os.path.join(host, "medgp_test"), "--cfg", cfg1, "--pan", "PT0001", "--thread", "1", "--fold", "0", "--kernclust-alg", "gmm",
+                            "--device", str(dev_index)], capture_output=True, text=True, timeout=600, cwd=cwd1)
+        wall_te = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError("medgp_test (config 1) rc %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:]))
+        out["config1_PT_INR_N150"] = {"patients": 1, "N": 150, "D": 2, "Q": 5, "R": 2, "H": 42, "random_init_num": 1000, "top_iteration_num": 40,
+                                      "train_process_wall_s": wall_tr, "gradient_evaluations": int(m1.group(1)) if m1 else None,
+                                      "test_process_wall_s": wall_te, "imputations_per_pass": [int(v) for v in re.findall(r"INFO: (\d+) imputations in", r.stdout)],
+                                      "config": "tests/golden/ref_cfg/PT_INR/exp_setup.json as the reference's config.py wrote it"}
         # ---- f3: 64 test patients, D = 4, N 120 .. 200, both passes (with / without the online hyper updates)
         P, D, Q, R = 64, 4, 3, 2
         pans = [f"C{k:03d}" for k in range(P)]

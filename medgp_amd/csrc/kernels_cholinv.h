@@ -65,16 +65,29 @@ struct CholInvSmem {
         double Dk[64][66];             // diagonal phase: in D, out L_kk (lower)
         double St[NW][16 * UPW][CI_ST];   // panel store: per-wave (16 UPW) x 16 slab that turns row-contiguous
                                        // 16-byte global accesses into the transposed accumulator layout
+#ifdef MEDGP_PRICE_NLML
+        // PRICING BUILD ONLY (results meaningless, never shipped; DESIGN_LOG R6): X_k aliased onto D_k so that the structure fits 40 KB
+        // -- what an nlml-only shape with packed triangular tiles would need -- to measure what 3 / 4 co-resident workgroups are worth
+        // before building them
+        double Xk[64][66];
+        double zpart[NW][64];
+    };
+#else
     };
     union {
         double Xk[64][66];         // L_kk^-1 (lower, exact zeros above the diagonal)
         double zpart[NW][64];      // end of the history GEMM of pass 0 (the previous step's Xk is dead, the factor has not
                                    // written the new one yet): the waves' partial z products; wave 0 sums them BEFORE it factors
     };
+#endif
     alignas(16) double rhs[64 + 128];          // diag(L_kk) during the factor (+ 128 doubles of diag16 scratch), then the z right-hand side
     double zk[64];                 // z of the current panel (for the in-step alpha accumulation)
+#ifdef MEDGP_PRICE_NLML
+    double zs[512];                // (pricing build: n <= 512 only)
+#else
     double zs[1024];               // z history kept in LDS for n <= 1024: the in-loop z product then issues no
                                    // global loads, whose wait (vmcnt) would also drain the operand loads
+#endif
     double red[16];
     double logdet;
     int fail;
@@ -83,6 +96,9 @@ struct CholInvSmem {
 #endif
 };
 static_assert(sizeof(CholInvSmem<4, 4>) <= 80 * 1024, "two 4-wave workgroups per CU need <= 80 KB each");
+#ifdef MEDGP_PRICE_NLML
+static_assert(sizeof(CholInvSmem<4, 2>) <= 40 * 1024 && sizeof(CholInvSmem<4, 3>) <= 53 * 1024, "pricing shapes: 4 / 3 workgroups per CU");
+#endif
 
 #define CI_S 66   // LDS row stride (doubles) of Dk / Xk
 // v_mfma_f64_16x16x4_f64 takes its last immediate (BLGP) as NEG[a, b, c]: 1 = the product enters with the opposite sign, for free
@@ -745,7 +761,9 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
                 if (wave == 0) diag_factor_wave((ld_t *)&sm.Dk[0][0], (ld_t *)&sm.Xk[0][0], (ld_t *)sm.rhs, (li_t *)&sm.fail, (ld_t *)&sm.logdet, lane);
                 __syncthreads();   // factor done: Dk = L_kk, Xk = L_kk^-1 (or fail)
                 STAMP(3);   // diagonal factor
+#ifndef MEDGP_PRICE_NLML
                 if (sm.fail) return false;
+#endif
                 if (wave == 0) {
                     // z_k = L_kk^-1 (y_k - zacc).  Xk has exact zeros above the diagonal, so fixed-length loops add the same terms
                     // as triangular ones, and the 64 terms are split over four independent accumulators (columns c, c+16, c+32,
@@ -876,7 +894,7 @@ __device__ bool cholinv_attempt(const MedgpDev &L, int b, int slot, int n, int w
 // (sel is a TEMPLATE parameter: as a run-time argument the extra entry paths moved hipcc's register allocation of the whole
 //  kernel -- one scratch reload inside the 64-MFMA chunk loop and three times the spill traffic in the panel solve of <4,4>)
 template <int NW, int UPW, int SEL>
-__global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int want_inv) {
+__global__ void __launch_bounds__(NW * 64, UPW == 3 ? 3 : 8 / UPW) k_cholinv(MedgpDev L, int want_inv) {
     constexpr int NT = NW * 64;
     constexpr int sel = SEL;
     __shared__ CholInvSmem<NW, UPW> sm;
@@ -896,7 +914,12 @@ __global__ void __launch_bounds__(NW * 64, 8 / UPW) k_cholinv(MedgpDev L, int wa
     }
     (void)sel;
     while (true) {
+#ifdef MEDGP_PRICE_NLML
+        (void)cholinv_attempt<NW, UPW>(L, b, slot, n, want_inv, sm);
+        break;
+#else
         if (cholinv_attempt<NW, UPW>(L, b, slot, n, want_inv, sm) && count >= L.dbg_fail) break;
+#endif
         __syncthreads();
         if (count >= 10) {   // ref: c_inference_exact.cpp:99,109-111
             if (tid == 0) L.status[b] = -1;

@@ -141,6 +141,7 @@ struct medgp_ctx {
     Arena arena[AR_COUNT];
     size_t mem_budget = (size_t)64 << 30;   // bytes of per-entry matrices one wave of a call may use (MEDGP_MEM_BUDGET_GB)
     size_t screen_budget = (size_t)2 << 30; // the same for one chunk of medgp_screen (MEDGP_SCREEN_BUDGET_GB)
+    long long screen_work = 32768;  // block pairs (sum nb^2) at which a medgp_screen chunk of look-ahead entries is closed (MEDGP_SCREEN_WORK)
     double alloc_s = 0.0;           // wall seconds inside device / pinned memory management calls (medgp_alloc_stats)
     long long alloc_calls = 0;
     int *d_bpos = nullptr;
@@ -641,6 +642,13 @@ int run_pipeline_one(medgp_ctx *c, hipStream_t stream, const MedgpDev &L, int nb
         // compiled ONCE for the tightest register budget among its callers -- with a <*,2> shape (four waves per SIMD, 128 VGPRs)
         // in the library it is held to 128 VGPRs and carries 182 scratch accesses on the serial path of EVERY shape (248 VGPRs and
         // 18 without; found when the legacy k_ci_panel caller that had masked this left the build: k_cholinv<4,4> 1.37 -> 1.48 ms).
+#ifdef MEDGP_PRICE_NLML
+        // pricing build (results meaningless): MEDGP_PRICE_SHAPE=43 / 42 runs the nlml-only calls in a shape with 3 / 4 workgroups per CU
+        static const int price_shape = getenv("MEDGP_PRICE_SHAPE") ? atoi(getenv("MEDGP_PRICE_SHAPE")) : 0;
+        if (want_mode == 0 && route == ROUTE_WG44 && price_shape == 43) hipLaunchKernelGGL((k_cholinv<4, 3, 0>), dim3(nbatch), dim3(256), 0, stream, L, want_mode);
+        else if (want_mode == 0 && route == ROUTE_WG44 && price_shape == 42) hipLaunchKernelGGL((k_cholinv<4, 2, 0>), dim3(nbatch), dim3(256), 0, stream, L, want_mode);
+        else
+#endif
         if (route == ROUTE_WG44) hipLaunchKernelGGL((k_cholinv<4, 4, 0>), dim3(nbatch), dim3(256), 0, stream, L, want_mode);
         else hipLaunchKernelGGL((k_cholinv<8, 4, 0>), dim3(nbatch), dim3(512), 0, stream, L, want_mode);
     }
@@ -757,10 +765,11 @@ void la_needs(const BatchPlan &P, const std::vector<LaNeed> &las, const std::vec
 // the patients' sizes in walk order (largest first).  A chunk holds at most max_batch entries and at most screen_budget bytes of
 // Gram matrices (8 ld^2 per entry: an nlml-only evaluation never forms U; ld taken at the upper end of the entry's size bucket, which
 // bounds the leading dimension of whatever class it lands in).  Entries of >= 45 blocks (64 MB of matrix each) take the look-ahead
-// schedule in any chunk this rule forms, and that schedule is saturated once a launch carries ~ 16 k block pairs (16 x N = 2048,
-// 4 x N = 4096, 2 x N = 5832: profiles/r04_route_table.txt): such a chunk is closed there -- N = 5832: 0.55 GB of
-// matrices + 0.28 GB of scratch per chunk where round 5 took 32 entries = 26 GB + 9 GB (obtaining that much memory cost seconds, see
-// struct Arena).  The budget (2 GB) still gives every size its efficient route: 1024 entries of N <= 512 (one workgroup each, two per
+// schedule in any chunk this rule forms, and that schedule gains little beyond ~ 32 k block pairs per launch (measured on the four
+// largest patients of the heavy-tailed cohort, N = 3258 .. 5832, 200 vectors each: 1234 / 1073 / 799 / 679 / 665 ms for chunks
+// closed at 4 / 8 / 16 / 32 / 64 k block pairs, scratch/screen_work_sweep.sh): such a chunk is closed there or by the byte budget --
+// N = 5832: 3 entries = 0.83 GB of matrices + 0.42 GB of scratch per chunk where round 5 took 32 entries = 26 GB + 9 GB (obtaining
+// that much memory can cost seconds, see struct Arena).  The budget (2 GB) still gives every size its efficient route: 1024 entries of N <= 512 (one workgroup each, two per
 // CU), 256 of N <= 1024 (one per CU), 64 of N <= 2048 (look-ahead schedule, saturated from 16 on).
 size_t screen_chunk_end(const medgp_ctx *c, const std::vector<int> &ns, int ninit, size_t e0, size_t total) {
     size_t e = e0, bytes = 0;
@@ -769,7 +778,7 @@ size_t screen_chunk_end(const medgp_ctx *c, const std::vector<int> &ns, int nini
         const int nb = blocks64(ns[e / ninit]);
         const size_t ldb = (size_t)64 << size_bucket(nb), per = 8 * ldb * ldb;
         if (e > e0 && bytes + per > c->screen_budget) break;
-        if (e > e0 && nb >= 45 && work >= 16384) break;
+        if (e > e0 && nb >= 45 && work >= c->screen_work) break;
         bytes += per; work += (long long)nb * nb; e++;
     }
     return e;
@@ -873,6 +882,7 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     { const char *e = getenv("MEDGP_WGRAD_DEEP"); c->wgrad_deep = e ? std::max(1, atoi(e)) : -1; }
     { const char *e = getenv("MEDGP_DEBUG_FAIL_ATTEMPTS"); c->dbg_fail = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_MEM_BUDGET_GB"); if (e && atof(e) > 0) c->mem_budget = (size_t)(atof(e) * 1073741824.0); }
+    { const char *e = getenv("MEDGP_SCREEN_WORK"); if (e && atoll(e) > 0) c->screen_work = atoll(e); }
     { const char *e = getenv("MEDGP_SCREEN_BUDGET_GB"); if (e && atof(e) > 0) c->screen_budget = (size_t)(atof(e) * 1073741824.0); }
     for (int i = 0; i < kAuxStreams; i++) {
         (void)hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);

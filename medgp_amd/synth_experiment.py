@@ -76,3 +76,38 @@ def make_experiment(root, pans, D=2, Q=3, R=2, N=60, prior_index=2, feature_inde
             w(opt["lower_bound_lengthscale"], opt["upper_bound_lengthscale"], Q)
     return {"cfg": cfg_file, "dirs": dirs, "stats": stats, "raw": raw, "opt": opt, "Q": Q, "D": D, "R": R,
             "feature_index": feature_index}
+
+
+CONFIG1_REL = os.path.join("tests", "golden", "ref_cfg", "PT_INR")
+CONFIG1_STATS = ((37.0, 4.0), (1.3, 0.4))     # (mean, std) of features 18 (PT) and 19 (INR): feature<idx>_stat.bin
+
+
+def reference_config1_tree(tmp, repo_root, pan="PT0001", n=150, seed=41):
+    """BASELINE config 1 on the REFERENCE-WRITTEN configuration (tests and bench.py's config-1 leg): copies tests/golden/ref_cfg/PT_INR
+    (exp_setup.json + hyp_bound.txt written by the reference's config.py, kernel/fold0/gmm_mode_* by its binaryIO.py) under `tmp`
+    KEEPING the relative paths the JSON names, and writes one synthetic patient with n / 2 + n / 2 observations next to it as
+    feature18.txt / feature19.txt + feature<idx>_stat.bin (count, then t / value pairs with 6 decimals; ref README.md:64-72).  The
+    hosts are then run with cwd = tmp and --cfg <returned relative path>, as the reference's CLI is run from its repository root.
+    Returns (cwd, cfg path relative to it, meta, t, y) with t / y as the loader reads them back (text round trip, z-scored in
+    double, narrowed to float: ref dataio/c_experiment.cpp:296-305)."""
+    import shutil
+    D = 2
+    dst = os.path.join(str(tmp), CONFIG1_REL)
+    shutil.copytree(os.path.join(repo_root, CONFIG1_REL), dst)
+    for sub in ("train", "test", "data", os.path.join("data", pan)):
+        os.makedirs(os.path.join(dst, sub), exist_ok=True)
+    m, t, y = synth.patient(seed, 0, D, n)
+    tl, yl = [], []
+    for j, fi in enumerate((18, 19)):
+        np.array(CONFIG1_STATS[j], np.float64).tofile(os.path.join(dst, "data", f"feature{fi}_stat.bin"))
+        tt = t[m == j]
+        vv = (y[m == j].astype(np.float64) * CONFIG1_STATS[j][1] + CONFIG1_STATS[j][0]).astype(np.float32)
+        with open(os.path.join(dst, "data", pan, f"feature{fi}.txt"), "w") as f:
+            f.write(f"{len(tt)}\n")
+            for a, b in zip(tt, vv):
+                f.write(f"{a:.6f}\n{b:.6f}\n")
+        t6 = np.array([np.float32(f"{a:.6f}") for a in tt], np.float32)
+        v6 = np.array([np.float32(f"{b:.6f}") for b in vv], np.float32)
+        tl.append(t6)
+        yl.append(((v6.astype(np.float64) - CONFIG1_STATS[j][0]) / CONFIG1_STATS[j][1]).astype(np.float32))
+    return str(tmp), os.path.join(CONFIG1_REL, "exp_setup.json"), m, np.concatenate(tl), np.concatenate(yl)
