@@ -58,6 +58,10 @@ struct BatchPlan {
     // need 296 GB) is run as consecutive WAVES of whole size classes that each fit it; the waves reuse the arenas in stream order.
     int nwaves = 1;
     bool with_u = true;        // laid out for Kmat AND Linv (false: an nlml-only plan, 8 ld^2 bytes per entry instead of 16)
+    // Lane base (medgp_screen's two lanes, round 6): the plan's entries use rows [row0, row0 + n) of the batch-indexed buffers and the
+    // arenas from these offsets on (doubles), so that two plans can be in flight on two streams at once.  0 for every other call.
+    int row0 = 0;
+    size_t mat0 = 0, vec0 = 0, tab0 = 0, la_part0 = 0, la_small0 = 0;
 };
 constexpr int kAuxStreams = 4;
 
@@ -181,6 +185,13 @@ struct medgp_ctx {
     int no_classes = 0;       // MEDGP_NO_CLASSES=1: rounds 1-4 behaviour -- one class per call, one route from its largest entry (A-B)
     hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
+    // second lane of medgp_screen (round 6): chunks alternate between c->stream and s_screen1, each with its own rows of the batch
+    // buffers and its own half of the arenas -- the assembly of one chunk runs beside the factorisation of the other
+    hipStream_t s_screen1 = nullptr;
+    hipEvent_t ev_fork1 = nullptr, ev_screen0 = nullptr, ev_screen1 = nullptr;
+    int screen_lanes = 2;           // MEDGP_SCREEN_LANES=1: one lane (rounds 1-5)
+    char *h_screen_tab = nullptr;   // pinned: the slot / position / theta-row tables of ALL chunks of one medgp_screen call
+    size_t screen_tab_cap = 0;
     std::vector<EvPair> events;
     std::vector<hipEvent_t> ev_pool;   // recycled timing events: a profiled launch creates none once the pool is warm
     double prof_ms[KID_COUNT] = {0};
@@ -394,20 +405,20 @@ int set_batch(medgp_ctx *c, int nbatch, const int32_t *slots, int *max_n_out, bo
 }
 
 // the view of the batch buffers one size class works in (entry 0 of the view = internal entry k.b0)
-MedgpDev class_view(const medgp_ctx *c, const SizeClass &k) {
+MedgpDev class_view(const medgp_ctx *c, const BatchPlan &P, const SizeClass &k) {
     const MedgpDev &L = c->dev;
     MedgpDev V = L;
-    const size_t Q = L.Q, D = L.D, b0 = k.b0;
+    const size_t Q = L.Q, D = L.D, b0 = (size_t)k.b0 + (size_t)P.row0;
     V.ldn = k.ld;
     V.slab_R = k.ld / 16 + (int)D; V.slab_C = k.ld / 64 + (int)D;
     V.slab_stride = (size_t)3 * Q * V.slab_R * V.slab_C;
     V.bslot = L.bslot + b0;
-    V.bpos = (c->plan.identity && c->plan.cls.size() == 1) ? nullptr : c->d_bpos + b0;
+    V.bpos = (P.identity && P.cls.size() == 1) ? nullptr : c->d_bpos + b0;
     V.tpos = c->tpos_on ? c->d_tpos + b0 : nullptr;
     V.hyp = L.hyp + b0 * L.hyp_stride;
-    V.cs = L.cs + k.off_tab; V.sn = L.sn + k.off_tab;
-    V.Kmat = L.Kmat + k.off_mat; V.Linv = L.Linv + k.off_mat;
-    V.z = L.z + k.off_vec; V.alpha = L.alpha + k.off_vec; V.wdiag = L.wdiag + k.off_vec;
+    V.cs = L.cs + P.tab0 + k.off_tab; V.sn = L.sn + P.tab0 + k.off_tab;
+    V.Kmat = L.Kmat + P.mat0 + k.off_mat; V.Linv = L.Linv + (P.with_u ? P.mat0 + k.off_mat : 0);
+    V.z = L.z + P.vec0 + k.off_vec; V.alpha = L.alpha + P.vec0 + k.off_vec; V.wdiag = L.wdiag + P.vec0 + k.off_vec;
     V.epi_lp = L.epi_lp + b0 * MEDGP_EPI_PARTS; V.epi_ticket = L.epi_ticket + b0;
     V.scal = L.scal + b0 * 4; V.status = L.status + b0; V.jit = L.jit + b0; V.bn = L.bn + b0; V.xk = L.xk + b0 * 64 * 64;
     V.S = L.S + b0 * Q * D * D; V.SM = L.SM + b0 * Q * D * D; V.SV = L.SV + b0 * Q * D * D;
@@ -437,7 +448,7 @@ MedgpDev shifted_view(const MedgpDev &L, int b0) {
 MedgpDev entry_view(const medgp_ctx *c, int b) {
     const int i = c->plan.inv[b];
     for (const SizeClass &k : c->plan.cls)
-        if (i >= k.b0 && i < k.b0 + k.count) return shifted_view(class_view(c, k), i - k.b0);
+        if (i >= k.b0 && i < k.b0 + k.count) return shifted_view(class_view(c, c->plan, k), i - k.b0);
     return c->dev;   // (not reached: every entry belongs to a class)
 }
 
@@ -476,6 +487,7 @@ int sync_ctx_streams(medgp_ctx *c) {
     for (int i = 0; i < kAuxStreams; i++) if (c->aux[i]) HIPCHK(c, hipStreamSynchronize(c->aux[i]));
     if (c->s_up) HIPCHK(c, hipStreamSynchronize(c->s_up));
     if (c->s_down) HIPCHK(c, hipStreamSynchronize(c->s_down));
+    if (c->s_screen1) HIPCHK(c, hipStreamSynchronize(c->s_screen1));
     return MEDGP_OK;
 }
 
@@ -531,15 +543,15 @@ int ensure_arena(medgp_ctx *c, size_t need_k, size_t need_u, size_t need_vec, si
 struct LaNeed { int count, nbmax, ld; LaArgs A; };
 inline size_t la_part_doubles(const LaNeed &e, bool with_u) { return (size_t)e.count * 2 * ((with_u ? 2 : 1) * e.nbmax + 1) * ((e.nbmax + LA_SLICE - 1) / LA_SLICE) * 4096; }
 inline size_t la_small_doubles(const LaNeed &e) { return (size_t)e.count * (64 * (size_t)e.ld + 5 * 2 * 4096 + 2 * (size_t)((e.nbmax + LA_SLICE - 1) / LA_SLICE) * 4096 + 1); }
-int ensure_la(medgp_ctx *c, std::vector<LaNeed> &v, bool with_u) {
+int ensure_la(medgp_ctx *c, std::vector<LaNeed> &v, bool with_u, size_t part0 = 0, size_t small0 = 0) {
     const size_t nring = 2;
-    size_t need_part = 0, need_small = 0;
+    size_t need_part = part0, need_small = small0;   // (part0 / small0: the lane base of the plan, doubles)
     for (const LaNeed &e : v) { need_part += la_part_doubles(e, with_u); need_small += la_small_doubles(e); }
     int rc;
-    // (fallback blocks only: the old scratch may still be read by queued kernels -- arena_ensure waits for the context's streams)
+    // (a block that must grow is replaced: arena_ensure waits for the context's streams first -- queued kernels may still read it)
     if ((rc = arena_ensure(c, AR_LA_PART, need_part * sizeof(double), 0, false, nullptr))) return rc;
     if ((rc = arena_ensure(c, AR_LA_SMALL, need_small * sizeof(double), 0, false, nullptr))) return rc;
-    double *pp = (double *)c->arena[AR_LA_PART].base, *ps = (double *)c->arena[AR_LA_SMALL].base;
+    double *pp = (double *)c->arena[AR_LA_PART].base + part0, *ps = (double *)c->arena[AR_LA_SMALL].base + small0;
     for (LaNeed &e : v) {
         LaArgs A{};
         const size_t nb = e.count;
@@ -784,22 +796,66 @@ size_t screen_chunk_end(const medgp_ctx *c, const std::vector<int> &ns, int nini
     return e;
 }
 
+// How medgp_screen cuts `total` = walk_n.size() * ninit entries into chunks, whether it runs them on two lanes, and what ONE lane needs of
+// every arena (doubles; the largest chunk, laid out once per distinct composition).  Shared with medgp_reserve_plan.
+struct ScreenChunk { size_t e0, e1; };
+struct ScreenCut {
+    std::vector<ScreenChunk> chunks;
+    bool two = false;
+    int lane_rows = 0;
+    size_t cap_mat = 0, cap_vec = 0, cap_tab = 0, cap_part = 0, cap_small = 0;
+};
+void screen_cut(medgp_ctx *c, const std::vector<int> &walk_n, int ninit, ScreenCut &S) {
+    const size_t total = walk_n.size() * (size_t)ninit;
+    const int saved_batch = c->max_batch;
+    S.two = c->screen_lanes >= 2 && c->max_batch >= 2 && screen_chunk_end(c, walk_n, ninit, 0, total) < total;
+    S.lane_rows = S.two ? c->max_batch / 2 : c->max_batch;
+    c->max_batch = S.lane_rows;   // (screen_chunk_end's entry cap)
+    S.chunks.clear();
+    for (size_t e0 = 0; e0 < total;) { const size_t e = screen_chunk_end(c, walk_n, ninit, e0, total); S.chunks.push_back({e0, e}); e0 = e; }
+    c->max_batch = saved_batch;
+    if (S.chunks.size() < 2) S.two = false;
+    BatchPlan P;
+    std::vector<LaNeed> las;
+    std::vector<int> la_of, en;
+    int lf = -1, ll = -1;
+    size_t lc = 0;
+    for (const ScreenChunk &ch : S.chunks) {
+        const int nf = walk_n[ch.e0 / ninit], nl = walk_n[(ch.e1 - 1) / ninit];
+        if (nf == nl && nf == lf && nl == ll && ch.e1 - ch.e0 == lc) continue;   // (runs of identical chunks: laid out once)
+        en.resize(ch.e1 - ch.e0);
+        for (size_t x = ch.e0; x < ch.e1; x++) en[x - ch.e0] = walk_n[x / ninit];
+        layout_plan(c, en.data(), (int)en.size(), false, P);
+        choose_routes(c, P, las, la_of);
+        size_t lp = 0, ls = 0;
+        la_needs(P, las, la_of, &lp, &ls);
+        S.cap_mat = std::max(S.cap_mat, P.need_mat); S.cap_vec = std::max(S.cap_vec, P.need_vec); S.cap_tab = std::max(S.cap_tab, P.need_tab);
+        S.cap_part = std::max(S.cap_part, lp); S.cap_small = std::max(S.cap_small, ls);
+        lf = nf; ll = nl; lc = ch.e1 - ch.e0;
+    }
+}
+
 // persist: the caller reads per-entry buffers of ALL entries after the call (factor exports, k_predict): such a call must fit one wave.
+// Pp / st_main / aux0, naux: the plan to run, the stream its first class runs on and the auxiliary streams its other classes may use --
+// the context's own (c->plan, c->stream, all of c->aux) unless medgp_screen runs two plans at once on two lanes.
 int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, int flag_grad, bool need_inverse, int min_n,
-                 double *nlml_dev, double *grad_dev, int32_t *status_dev, bool store_ukk = false, bool persist = false) {
+                 double *nlml_dev, double *grad_dev, int32_t *status_dev, bool store_ukk = false, bool persist = false,
+                 BatchPlan *Pp = nullptr, hipStream_t st_main = nullptr, int aux0 = 0, int naux = kAuxStreams, hipEvent_t ev_fork_in = nullptr) {
     (void)max_n; (void)nbatch;
-    BatchPlan &P = c->plan;
+    BatchPlan &P = Pp ? *Pp : c->plan;
+    if (!st_main) st_main = c->stream;
+    hipEvent_t ev_fork = ev_fork_in ? ev_fork_in : c->ev_fork;
     const bool forms_u = flag_grad || need_inverse || store_ukk;
     if (forms_u && !P.with_u) return fail(c, MEDGP_ERR_ARG, "internal: plan laid out without Linv for a call that forms it");
     if (persist && P.nwaves > 1)
         return fail(c, MEDGP_ERR_CAPACITY, "the call's per-entry matrices exceed the memory budget of %zu GB (MEDGP_MEM_BUDGET_GB) and its outputs need all of them at once: split the call",
                     c->mem_budget >> 30);
-    { int rc = ensure_arena(c, P.need_mat, P.with_u ? P.need_mat : 0, P.need_vec, P.need_tab, P.need_slab); if (rc) return rc; }
+    { int rc = ensure_arena(c, P.mat0 + P.need_mat, P.with_u ? P.mat0 + P.need_mat : 0, P.vec0 + P.need_vec, P.tab0 + P.need_tab, P.need_slab); if (rc) return rc; }
     c->last_has_inverse = (flag_grad || need_inverse) && P.nwaves == 1;
     std::vector<LaNeed> las;
     std::vector<int> la_of;
     choose_routes(c, P, las, la_of);
-    const int nstr = std::min(c->class_streams, kAuxStreams);
+    const int nstr = std::max(0, std::min(c->class_streams, naux));
     for (int w = 0; w < P.nwaves; w++) {
         // this wave's classes [i0, i1) and their look-ahead scratch
         size_t i0 = 0, i1;
@@ -809,29 +865,29 @@ int run_pipeline(medgp_ctx *c, int nbatch, int max_n, const double *theta_dev, i
         std::vector<LaNeed> wl;
         std::vector<int> wl_of(P.cls.size(), -1);
         for (size_t i = i0; i < i1; i++) if (la_of[i] >= 0) { wl_of[i] = (int)wl.size(); wl.push_back(las[la_of[i]]); }
-        if (!wl.empty()) { int rc = ensure_la(c, wl, P.with_u); if (rc) return rc; }
-        const bool fork = i1 - i0 > 1 && c->class_streams > 0 && c->aux[0];
-        if (fork) HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        if (!wl.empty()) { int rc = ensure_la(c, wl, P.with_u, P.la_part0, P.la_small0); if (rc) return rc; }
+        const bool fork = i1 - i0 > 1 && nstr > 0 && c->aux[aux0];
+        if (fork) HIPCHK(c, hipEventRecord(ev_fork, st_main));
         bool used[kAuxStreams] = {false, false, false, false};
         for (size_t i = i0; i < i1; i++) {
             const SizeClass &k = P.cls[i];
-            hipStream_t st = c->stream;
+            hipStream_t st = st_main;
             int ai = -1;
             if (fork && i > i0) {   // the wave's first class (its largest entries) stays on the call's stream
-                ai = (int)((i - i0 - 1) % nstr);
+                ai = aux0 + (int)((i - i0 - 1) % nstr);
                 st = c->aux[ai];
-                if (!used[ai]) { HIPCHK(c, hipStreamWaitEvent(st, c->ev_fork, 0)); used[ai] = true; }
+                if (!used[ai]) { HIPCHK(c, hipStreamWaitEvent(st, ev_fork, 0)); used[ai] = true; }
             }
-            const MedgpDev V = class_view(c, k);
+            const MedgpDev V = class_view(c, P, k);
             int rc = run_pipeline_one(c, st, V, k.count, k.nbmax, theta_dev, flag_grad, need_inverse, min_n, nlml_dev, grad_dev, status_dev, store_ukk,
                                       P.en.data() + k.b0, k.route, wl_of[i] >= 0 ? &wl[wl_of[i]].A : nullptr);
             if (rc) return rc;
         }
         if (fork)
-            for (int ai = 0; ai < nstr; ai++)
+            for (int ai = aux0; ai < aux0 + nstr; ai++)
                 if (used[ai]) {
                     HIPCHK(c, hipEventRecord(c->ev_join[ai], c->aux[ai]));
-                    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join[ai], 0));
+                    HIPCHK(c, hipStreamWaitEvent(st_main, c->ev_join[ai], 0));
                 }
     }
     return MEDGP_OK;
@@ -882,6 +938,7 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     { const char *e = getenv("MEDGP_WGRAD_DEEP"); c->wgrad_deep = e ? std::max(1, atoi(e)) : -1; }
     { const char *e = getenv("MEDGP_DEBUG_FAIL_ATTEMPTS"); c->dbg_fail = e ? atoi(e) : 0; }
     { const char *e = getenv("MEDGP_MEM_BUDGET_GB"); if (e && atof(e) > 0) c->mem_budget = (size_t)(atof(e) * 1073741824.0); }
+    { const char *e = getenv("MEDGP_SCREEN_LANES"); if (e && atoi(e) >= 1) c->screen_lanes = std::min(2, atoi(e)); }
     { const char *e = getenv("MEDGP_SCREEN_WORK"); if (e && atoll(e) > 0) c->screen_work = atoll(e); }
     { const char *e = getenv("MEDGP_SCREEN_BUDGET_GB"); if (e && atof(e) > 0) c->screen_budget = (size_t)(atof(e) * 1073741824.0); }
     for (int i = 0; i < kAuxStreams; i++) {
@@ -889,6 +946,8 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
         (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
     }
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    (void)hipStreamCreateWithFlags(&c->s_screen1, hipStreamNonBlocking);
+    for (hipEvent_t *e : {&c->ev_fork1, &c->ev_screen0, &c->ev_screen1}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->num_cu = pr.multiProcessorCount; }
     *out = c;
     return MEDGP_OK;
@@ -906,6 +965,9 @@ void medgp_destroy(medgp_ctx *c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->s_screen1) { (void)hipStreamSynchronize(c->s_screen1); (void)hipStreamDestroy(c->s_screen1); }
+    for (hipEvent_t e : {c->ev_fork1, c->ev_screen0, c->ev_screen1}) if (e) (void)hipEventDestroy(e);
+    if (c->h_screen_tab) (void)hipHostFree(c->h_screen_tab);
     for (hipStream_t st : {c->s_up, c->s_down}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (int i = 0; i < 2; i++) { if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]); if (c->ev_k[i]) (void)hipEventDestroy(c->ev_k[i]); }
     if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
@@ -1074,23 +1136,13 @@ int medgp_reserve_plan(medgp_ctx *c, int count, const int32_t *n, int ninit) {
     };
     // (a) one nlml + gradient call over the announced patients (the largest max_batch of them)
     take(ns.data(), std::min(count, c->max_batch), true);
-    // (b) the chunks medgp_screen forms of them
+    // (b) the chunks medgp_screen forms of them (two lanes: twice the largest chunk)
     if (ninit > 0) {
-        const size_t total = (size_t)count * ninit;
-        std::vector<int> en;
-        int last_first = -1, last_last = -1;
-        size_t last_cnt = 0;
-        for (size_t e0 = 0; e0 < total;) {
-            const size_t e = screen_chunk_end(c, ns, ninit, e0, total);
-            const int nf = ns[e0 / ninit], nl = ns[(e - 1) / ninit];
-            if (!(nf == nl && nf == last_first && nl == last_last && e - e0 == last_cnt)) {   // (runs of identical chunks: laid out once)
-                en.resize(e - e0);
-                for (size_t x = e0; x < e; x++) en[x - e0] = ns[x / ninit];
-                take(en.data(), (int)en.size(), false);
-                last_first = nf; last_last = nl; last_cnt = e - e0;
-            }
-            e0 = e;
-        }
+        ScreenCut SC;
+        screen_cut(c, ns, ninit, SC);
+        const size_t f = SC.two ? 2 : 1;
+        nk = std::max(nk, f * SC.cap_mat); nvec = std::max(nvec, f * SC.cap_vec); ntab = std::max(ntab, f * SC.cap_tab);
+        npart = std::max(npart, f * SC.cap_part); nsmall = std::max(nsmall, f * SC.cap_small);
     }
     int rc;
     if ((rc = ensure_arena(c, nk, nu, nvec, ntab, nslab, true))) return rc;
@@ -1419,37 +1471,94 @@ int medgp_screen(medgp_ctx *c, int nslots, const int32_t *slots, int ninit, cons
     std::vector<int> perm(nslots);
     for (int s = 0; s < nslots; s++) perm[s] = s;
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return c->h_n[slots[a]] > c->h_n[slots[b]]; });
-    // chunks of consecutive (patient, init) entries (screen_chunk_end)
     std::vector<int> walk_n(nslots);
     for (int s = 0; s < nslots; s++) walk_n[s] = c->h_n[slots[perm[s]]];
+    // ---- chunks of consecutive (patient, vector) entries (screen_chunk_end).  ONE chunk (everything fits one call): the context's own
+    // plan on its own stream, exactly the call medgp_nlml_grad(flag_grad = 0) makes of the same entries.  SEVERAL chunks: they
+    // alternate between two LANES -- two streams, each with its own rows of the batch-indexed buffers, its own half of the arenas and
+    // its own auxiliary streams -- so that the assembly of one chunk (fp64 VALU bound) runs beside the factorisation of the other (MFMA
+    // + latency bound) and the tail of one chunk's launch is filled by the other's.  Measured before it was built, with two contexts
+    // screening the same patient at once: 2.24 against 2.48 ms per 1000 evaluations at N = 512 (scratch/screen_two_ctx.py).  A chunk of a
+    // two-lane call holds at most max_batch / 2 entries (its rows of the buffers).
+    ScreenCut SC;
+    screen_cut(c, walk_n, ninit, SC);
+    const bool two = SC.two;
+    const std::vector<ScreenChunk> &chunks = SC.chunks;
+    const int lane_rows = SC.lane_rows;
+    const size_t cap_mat = SC.cap_mat, cap_vec = SC.cap_vec, cap_tab = SC.cap_tab, cap_part = SC.cap_part, cap_small = SC.cap_small;
+    BatchPlan lane_plan[2];
+    if (two) {
+        int rc0;
+        if ((rc0 = ensure_arena(c, 2 * cap_mat, 0, 2 * cap_vec, 2 * cap_tab, 0))) return rc0;
+        if (cap_part && (rc0 = arena_ensure(c, AR_LA_PART, 2 * cap_part * sizeof(double), 0, false, nullptr))) return rc0;
+        if (cap_small && (rc0 = arena_ensure(c, AR_LA_SMALL, 2 * cap_small * sizeof(double), 0, false, nullptr))) return rc0;
+        // the tables of ALL chunks in one pinned block: a lane's copies read their own region, which nobody rewrites during the call
+        // (the two-buffer upload ring is guarded by events on c->stream only)
+        const size_t tab_bytes = sizeof(int) * 3 * total;
+        if (tab_bytes > c->screen_tab_cap) {
+            { int rcs = sync_ctx_streams(c); if (rcs) return rcs; }
+            if (c->h_screen_tab) (void)hipHostFree(c->h_screen_tab);
+            c->h_screen_tab = nullptr; c->screen_tab_cap = 0;
+            HIPCHK(c, hipHostMalloc((void **)&c->h_screen_tab, tab_bytes + tab_bytes / 4, hipHostMallocDefault));
+            c->screen_tab_cap = tab_bytes + tab_bytes / 4;
+        }
+        // lane 1 starts behind everything queued on the context's stream so far (the theta block, earlier calls that use the arenas)
+        HIPCHK(c, hipEventRecord(c->ev_screen0, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->s_screen1, c->ev_screen0, 0));
+    }
     std::vector<int32_t> cs;
-    std::vector<int> tp;
-    size_t e0 = 0;
+    std::vector<int> tp, en;
     int rc = MEDGP_OK;
     c->tpos_on = true;
-    while (e0 < total && rc == MEDGP_OK) {
+    for (size_t ci = 0; ci < chunks.size() && rc == MEDGP_OK; ci++) {
+        const size_t e0 = chunks[ci].e0, e1 = chunks[ci].e1;
+        const int nb = (int)(e1 - e0);
         cs.clear(); tp.clear();
-        const size_t e = screen_chunk_end(c, walk_n, ninit, e0, total);
-        for (size_t x = e0; x < e; x++) { cs.push_back(slots[perm[x / ninit]]); tp.push_back((int)(x % ninit)); }
-        const int nb = (int)cs.size();
-        int max_n = 0;
-        if ((rc = set_batch(c, nb, cs.data(), &max_n, false, false))) break;
-        {   // theta rows in the plan's internal order
-            void *pin = nullptr;
-            if ((rc = pin_stage(c, sizeof(int) * nb, &pin))) break;
-            int *hp = (int *)pin;
-            for (int i = 0; i < nb; i++) hp[i] = tp[c->plan.order[i]];
-            hipError_t he = hipMemcpyAsync(c->d_tpos, hp, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream);
+        for (size_t x = e0; x < e1; x++) { cs.push_back(slots[perm[x / ninit]]); tp.push_back((int)(x % ninit)); }
+        hipError_t he = hipSuccess;
+        if (!two) {
+            int max_n = 0;
+            if ((rc = set_batch(c, nb, cs.data(), &max_n, false, false))) break;
+            {   // theta rows in the plan's internal order
+                void *pin = nullptr;
+                if ((rc = pin_stage(c, sizeof(int) * nb, &pin))) break;
+                int *hp = (int *)pin;
+                for (int i = 0; i < nb; i++) hp[i] = tp[c->plan.order[i]];
+                he = hipMemcpyAsync(c->d_tpos, hp, sizeof(int) * nb, hipMemcpyHostToDevice, c->stream);
+                if (he != hipSuccess) { rc = fail(c, MEDGP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)); break; }
+            }
+            if ((rc = run_pipeline(c, nb, max_n, c->d_screen_theta, 0, false, 3, c->d_nlml, nullptr, c->d_status_out))) break;
+            he = hipMemcpyAsync(hn + e0, c->d_nlml, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(hs + e0, c->d_status_out, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream);
+        } else {
+            const int lane = (int)(ci & 1);
+            hipStream_t st = lane ? c->s_screen1 : c->stream;
+            BatchPlan &P = lane_plan[lane];
+            en.resize(nb);
+            for (int i = 0; i < nb; i++) en[i] = c->h_n[cs[i]];
+            layout_plan(c, en.data(), nb, false, P);
+            P.row0 = lane * lane_rows;
+            P.mat0 = lane * cap_mat; P.vec0 = lane * cap_vec; P.tab0 = lane * cap_tab; P.la_part0 = lane * cap_part; P.la_small0 = lane * cap_small;
+            int *hb = (int *)c->h_screen_tab + 3 * e0, *hpz = hb + nb, *ht = hpz + nb;
+            for (int i = 0; i < nb; i++) { hb[i] = cs[P.order[i]]; hpz[i] = P.order[i]; ht[i] = tp[P.order[i]]; }
+            he = hipMemcpyAsync(c->d_bslot + P.row0, hb, sizeof(int) * nb, hipMemcpyHostToDevice, st);
+            if (he == hipSuccess) he = hipMemcpyAsync(c->d_bpos + P.row0, hpz, sizeof(int) * nb, hipMemcpyHostToDevice, st);
+            if (he == hipSuccess) he = hipMemcpyAsync(c->d_tpos + P.row0, ht, sizeof(int) * nb, hipMemcpyHostToDevice, st);
             if (he != hipSuccess) { rc = fail(c, MEDGP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)); break; }
+            if ((rc = run_pipeline(c, nb, 0, c->d_screen_theta, 0, false, 3, c->d_nlml + P.row0, nullptr, c->d_status_out + P.row0, false, false,
+                                   &P, st, lane * (kAuxStreams / 2), kAuxStreams / 2, lane ? c->ev_fork1 : c->ev_fork))) break;
+            he = hipMemcpyAsync(hn + e0, c->d_nlml + P.row0, sizeof(double) * nb, hipMemcpyDeviceToHost, st);
+            if (he == hipSuccess) he = hipMemcpyAsync(hs + e0, c->d_status_out + P.row0, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, st);
         }
-        if ((rc = run_pipeline(c, nb, max_n, c->d_screen_theta, 0, false, 3, c->d_nlml, nullptr, c->d_status_out))) break;
-        hipError_t he = hipMemcpyAsync(hn + e0, c->d_nlml, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream);
-        if (he == hipSuccess) he = hipMemcpyAsync(hs + e0, c->d_status_out, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, c->stream);
         if (he != hipSuccess) { rc = fail(c, MEDGP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)); break; }
-        e0 = e;
     }
     c->tpos_on = false;
     c->last_nbatch = 0;   // (the cached plan carries this call's theta rows: the next call lays its own out)
+    if (two) {
+        c->plan = lane_plan[0];   // (diagnostics: medgp_last_plan reports lane 0's last chunk)
+        c->last_has_inverse = false;
+        HIPCHK(c, hipStreamSynchronize(c->s_screen1));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (rc) return rc;
     for (int sp = 0; sp < nslots; sp++) {   // walk order -> the caller's rows
@@ -1615,7 +1724,7 @@ static int fit_predict_impl(medgp_ctx *c, int nbatch, const int32_t *slots, cons
     if ((rc = run_pipeline(c, nbatch, max_n, c->d_theta, 0, false, 1, nullptr, nullptr, nullptr, true, true))) return rc;
     for (const SizeClass &k : c->plan.cls) {   // (behind the join of the classes' chains: one launch per class view)
         Launcher l(c, KID_PREDICT);
-        hipLaunchKernelGGL(k_predict, dim3(nstar, k.count), dim3(256), 0, c->stream, class_view(c, k), nstar, c->d_meta2, c->d_t2, c->d_ks, c->d_mean, c->d_var);
+        hipLaunchKernelGGL(k_predict, dim3(nstar, k.count), dim3(256), 0, c->stream, class_view(c, c->plan, k), nstar, c->d_meta2, c->d_t2, c->d_ks, c->d_mean, c->d_var);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(mean, c->d_mean, sizeof(float) * ntot, hipMemcpyDeviceToHost, c->stream));
