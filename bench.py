@@ -51,7 +51,27 @@ def alg_work(kernel, N, Q, D, H):
     return table.get(kernel, (0.0, 0.0, "hbm"))
 
 
-def leg_roofline(kernel_ms, N, Q, D, H, P, nlml_only=False):
+def shape_traffic(label, kernel):
+    """HBM bytes per launch of `kernel` on another measured shape (profiles/rNN_pmc_summary.json "_shapes", round 6), or None when the
+    device sources have changed since the passes.  For k_la_step the per-call figure is the sum over its launches: mean x launches per call
+    is formed by the caller."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))
+    if not cands:
+        return None
+    try:
+        d = json.load(open(cands[-1]))
+    except (OSError, ValueError):
+        return None
+    if d.get("_meta", {}).get("csrc_sha256") != csrc_digest():
+        return None
+    e = d.get("_shapes", {}).get(label, {}).get(kernel)
+    if not e or "write_bytes" not in e:
+        return None
+    return e["fetch_bytes_x2_if_wide_loads"] + e["write_bytes"]
+
+
+def leg_roofline(kernel_ms, N, Q, D, H, P, nlml_only=False, shape=None, launches=1):
     """Roofline fraction of the DOMINANT kernel of an auxiliary leg (verdict r5 item 6): its algorithmic flops (alg_work x the P
     entries of the call; nlml only: no inverse, N^3/3 + 2 N^2 per entry) / its HIP-event time per call / fp64 peak.  For the
     look-ahead schedule the time is the sum over the N / 64 launches of k_la_step."""
@@ -64,7 +84,12 @@ def leg_roofline(kernel_ms, N, Q, D, H, P, nlml_only=False):
     ms = kernel_ms[dom]
     if bound == "mfma":
         ach = flop * P / (ms * 1e-3) / 1e12
-        return {"kernel": dom, "ms_per_call": ms, "bound": "mfma", "achieved": ach, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS}
+        r = {"kernel": dom, "ms_per_call": ms, "bound": "mfma", "achieved": ach, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS}
+        tr = shape_traffic(shape, {"k_la_step": "k_la_step", "k_cholinv": "k_cholinv"}.get(dom, dom)) if shape else None
+        if tr:
+            tr *= launches      # (bytes per launch x launches of this kernel per call)
+            r.update({"traffic": tr, "hbm_frac": tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic_ratio": tr / (byts * P)})
+        return r
     ach = byts * P / (ms * 1e-3) / 1e9
     return {"kernel": dom, "ms_per_call": ms, "bound": "hbm", "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
 
@@ -251,11 +276,13 @@ def other_configs(dev_index, seed, reps=5):
         f_alg = N ** 3 + 6 * N * N + 80 * Q * N * (N + 1) / 2
         out[name] = {"patients": P, "N": N, "D": D, "Q": Q, "R": R, "H": H, "ms_per_call": 1e3 * dt, "evals_per_s": P / dt,
                      "frac_fp64_peak": f_alg * P / dt / 1e12 / FP64_PEAK_TFLOPS, "kernel_ms": prof,
-                     "dominant_kernel": leg_roofline(prof, N, Q, D, H, P)}
+                     "dominant_kernel": leg_roofline(prof, N, Q, D, H, P, shape="config3_1xN2048" if name == "config3_1xN2048_D24" else None,
+                                                     launches=N // 64 if name == "config3_1xN2048_D24" else 1)}
         ctx.close()
 
     for shp in shapes:
         guarded(shp[0], lambda shp=shp: one_shape(*shp))
+    guarded("config3_patient_inside_a_lockstep_batch", lambda: config3_in_batch(out, dev_index, seed, reps))
     guarded("screening_1000xN512_D24_nlml_only", lambda: screening(out, dev_index, seed, reps))
     guarded("config4_full_4096xN512_D24", lambda: config4_full(out, dev_index, seed))
     guarded("cohort_mode_kde_P4096_D24_one_cluster", lambda: cohort_kde(out, dev_index, seed))
@@ -315,6 +342,36 @@ def ragged_cohort(out, dev_index, seed, reps=5):
                                               "speedup_vs_before": (res["before"]["ms_per_call"] if "before" in res else 572.5) / res["after"]["ms_per_call"]}
 
 
+def config3_in_batch(out, dev_index, seed, reps):
+    """What BASELINE config 3's lone N = 2048 patient costs where the reference's workload actually puts it (verdict r5 item 8): inside a
+    lock-step batch of a cohort -- 255 patients of N = 263 (the heavy-tailed cohort's median) + the one of N = 2048, one nlml + gradient
+    call, size classes on separate streams.  marginal = (call with it) - (call without it); standalone it is latency bound (0.86 ms,
+    0.14 of peak: the diagonal chain of 32 look-ahead steps), in the batch the bulk's workgroups fill the CUs its chain leaves idle.
+    ref for the workload: the job generator buckets patients by size, scripts/slurm_della.json:6-62."""
+    import medgp_amd
+    from medgp_amd import synth
+    D, Q, R, NS, NL, PS = 24, 5, 8, 263, 2048, 255
+    pts = [synth.patient(seed + 7, p, D, NS) for p in range(PS)] + [synth.patient(seed + 7, PS, D, NL)]
+    th = np.stack([synth.theta(seed + 7, p, 7, Q, D, R) for p in range(PS + 1)])
+    ctx = medgp_amd.Context(7, Q, D, R, device=dev_index)
+    ctx.reserve(PS + 1, NL, PS + 1)
+    ctx.set_patients(np.arange(PS + 1), pts)
+    ctx.set_prior(-1, *synth.hier_gamma_prior(Q, D, R, 0.01))
+    ctx.reserve_plan([NS] * PS + [NL])
+    res = {}
+    for name, sl in (("bulk_255xN263", np.arange(PS)), ("bulk_plus_1xN2048", np.arange(PS + 1)), ("alone_1xN2048", np.array([PS]))):
+        nl, g, st = ctx.nlml_grad(sl, th[sl], True)
+        assert np.all(st >= 0) and np.all(np.isfinite(nl)), name
+        ctx.nlml_grad(sl, th[sl], True)
+        t0 = time.perf_counter()
+        for _ in range(4 * reps):
+            ctx.nlml_grad(sl, th[sl], True)
+        res[name] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / (4 * reps), "plan_count_blocks_route": ctx.last_plan()}
+    ctx.close()
+    out["config3_patient_inside_a_lockstep_batch"] = {**res, "marginal_ms_of_the_N2048_patient": res["bulk_plus_1xN2048"]["ms_per_call"] - res["bulk_255xN263"]["ms_per_call"],
+                                                      "standalone_ms": res["alone_1xN2048"]["ms_per_call"]}
+
+
 def screening(out, dev_index, seed, reps):
     import medgp_amd
     from medgp_amd import synth
@@ -338,17 +395,23 @@ def screening(out, dev_index, seed, reps):
     prof = {k: round(v[0], 4) for k, v in ctx.profile_read().items() if v[1] > 0}
     out["screening_1000xN512_D24_nlml_only"] = {"evaluations": P, "N": N, "D": D, "ms_per_call": 1e3 * dt, "evals_per_s": P / dt,
                                                 "frac_fp64_peak": (N ** 3 / 3 + 2 * N * N + 40 * Q * N * (N + 1) / 2) * P / dt / 1e12 / FP64_PEAK_TFLOPS,
-                                                "kernel_ms": prof, "dominant_kernel": leg_roofline(prof, N, Q, D, synth.num_hyp(7, Q, D, R), P, nlml_only=True)}
-    # the same 1000 evaluations through medgp_screen (the entry point the trainer uses: theta block uploaded once, chunks queued without
-    # a host wait)
-    th1 = th
-    ctx.screen(np.zeros(1, dtype=np.int32), th1)
+                                                "kernel_ms": prof, "dominant_kernel": leg_roofline(prof, N, Q, D, synth.num_hyp(7, Q, D, R), P, nlml_only=True, shape="screening_1000xN512_nlml_only")}
+    ctx.close()
+    # the same evaluations through medgp_screen, the entry point the trainer uses (hyper block uploaded once, chunks queued without a
+    # host wait, alternating between two lanes): 8 patients x 1000 vectors through max_batch 1024
+    P8 = 8
+    ctx = medgp_amd.Context(7, Q, D, R, device=dev_index)
+    ctx.reserve(P8, N, 1024)
+    ctx.set_patients(np.arange(P8), [synth.patient(seed + 2, p, D, N) for p in range(P8)])
+    ctx.reserve_plan([N] * P8, P)
+    nl8, st8 = ctx.screen(np.arange(P8), th)
+    assert np.all(st8 >= 0) and np.array_equal(nl8[0], nl)            # patient 0: the bits of the call above
     t0 = time.perf_counter()
     for _ in range(reps):
-        ctx.screen(np.zeros(1, dtype=np.int32), th1)
+        ctx.screen(np.arange(P8), th)
     dts = (time.perf_counter() - t0) / reps
-    out["screening_1000xN512_D24_nlml_only"]["medgp_screen_ms_per_call"] = 1e3 * dts
-    out["screening_1000xN512_D24_nlml_only"]["medgp_screen_evals_per_s"] = P / dts
+    out["screening_1000xN512_D24_nlml_only"].update({"medgp_screen_8_patients_ms_per_1000": 1e3 * dts / P8, "medgp_screen_evals_per_s": P8 * P / dts,
+                                                      "medgp_screen_frac_fp64_peak": (N ** 3 / 3 + 2 * N * N + 40 * Q * N * (N + 1) / 2) * P8 * P / dts / 1e12 / FP64_PEAK_TFLOPS})
     ctx.close()
 
 

@@ -38,7 +38,7 @@ for t in ('fetch', 'write', 'mfma', 'sq'):
     for k, v in d.items():
         out.setdefault(k, {}).update({c: {"mean_per_launch": sum(x) / len(x), "launches": len(x)} for c, x in v.items()})
 for k, v in out.items():
-    if k == '_meta': continue
+    if k.startswith('_'): continue
     if 'FETCH_SIZE' in v:
         f = v['FETCH_SIZE']['mean_per_launch'] * 1024
         w = v['WRITE_SIZE']['mean_per_launch'] * 1024
@@ -52,12 +52,44 @@ for k, v in out.items():
             "valu_wave_instructions": v['SQ_INSTS_VALU']['mean_per_launch'],
             "valu_issue_frac_of_1024_simds": v['SQ_INSTS_VALU']['mean_per_launch'] * 4 / (1024 * cyc),
             "wait_any_frac_of_wave_cycles": v['SQ_WAIT_ANY']['mean_per_launch'] / v['SQ_WAVE_CYCLES']['mean_per_launch'] if 'SQ_WAVE_CYCLES' in v else None})
+# round 6: other shapes (scratch/gpurun_prof.sh): steady-state launch time from the kernel trace + FETCH_SIZE / WRITE_SIZE per launch, per kernel
+shapes = {}
+for name, label in (("screen", "screening_1000xN512_nlml_only"), ("cfg3", "config3_1xN2048")):
+    trs = glob.glob(f'gpurun_out/prof_{tag}_{name}_trace/runc/*_kernel_trace.csv')
+    if not trs:
+        continue
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(trs[0])):
+        per[r['Kernel_Name'].split('(')[0].replace('void ', '')].append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+    cnt = {}
+    for t in ('fetch', 'write'):
+        ps = glob.glob(f'gpurun_out/prof_{tag}_{name}_{t}/runc/*_counter_collection.csv')
+        if not ps:
+            continue
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(ps[0])):
+            if not r['Kernel_Name'].startswith('__amd'):
+                d[r['Kernel_Name'].split('(')[0].replace('void ', '')].append(float(r['Counter_Value']))
+        cnt[t] = {k: (sum(v) / len(v), len(v)) for k, v in d.items()}
+    sh = {}
+    for k, v in per.items():
+        v.sort()
+        d = sorted(x[1] for x in v[min(len(v) - 1, len(v) // 4):])       # the first quarter of the launches are warm-up steps
+        e = {"median_ns": d[len(d) // 2], "mean_ns": sum(d) / len(d), "launches_used": len(d)}
+        if k in cnt.get('fetch', {}) and k in cnt.get('write', {}):
+            f, w = cnt['fetch'][k][0] * 1024, cnt['write'][k][0] * 1024
+            e.update({"fetch_bytes_raw": f, "fetch_bytes_x2_if_wide_loads": 2 * f, "write_bytes": w})
+        sh[k] = e
+    shapes[label] = sh
+    shutil.copy(glob.glob(f'gpurun_out/prof_{tag}_{name}_trace/runc/*_kernel_stats.csv')[0], f'profiles/{rnd}_kernel_stats_{name}.csv')
+if shapes:
+    out['_shapes'] = shapes
 import bench
 out['_meta'] = {'git_commit': subprocess.run(['git', 'rev-parse', 'HEAD'], capture_output=True, text=True).stdout.strip(),
                 'csrc_sha256': bench.csrc_digest(), 'command': 'python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra (one rocprofv3 --pmc pass per counter group)'}
 json.dump(out, open(f'profiles/{rnd}_pmc_summary.json', 'w'), indent=1)
 for k, v in out.items():
-    if k == '_meta': continue
+    if k.startswith('_'): continue
     print(k, {a: (round(b, 3) if isinstance(b, float) and b < 10 else int(b)) for a, b in v.get('derived', {}).items()})
 print(open(f'profiles/{rnd}_kernel_stats.csv').read()[:1100])
 if tr:

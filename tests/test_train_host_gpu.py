@@ -298,3 +298,39 @@ def test_single_output_families_through_both_hosts(tmp_path, built_lib, kernel_i
             assert gp.size == t.size
             np.testing.assert_allclose(gp, pred, rtol=2e-5, atol=2e-6)
             np.testing.assert_allclose(ge, err, rtol=2e-5, atol=2e-6)
+
+
+def test_train_skips_an_unreadable_patient_and_keeps_going(tmp_path, built_lib):
+    """Advisor finding (round 5): one unreadable patient file -- or a patient larger than the list announced -- used to end the whole
+    long-lived trainer in the middle of the run, dropping every resident patient's progress.  Now such a patient is skipped like one with
+    too few samples (flag 0 through finish(), ref: main_one_train.cpp:185-201 for the flag files), everybody else is trained to the same
+    bytes as without it, and the exit status is non-zero at the end (what medgp_test does with n_unreadable)."""
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", HOST, "medgp_train"])
+    pans = [f"P{k:03d}" for k in range(6)]
+    Ns = [60, 75, 48, 52, 64, 70]
+    ref = make_experiment(tmp_path / "ref", pans, D=2, Q=3, R=2, N=Ns, prior_index=2)
+    bad = make_experiment(tmp_path / "bad", pans, D=2, Q=3, R=2, N=Ns, prior_index=2)
+    os.remove(os.path.join(bad["dirs"]["data"], "P002", "feature19.txt"))        # unreadable: a feature file is missing
+    lists = {}
+    for tag, ex in (("ref", ref), ("bad", bad)):
+        plist = tmp_path / f"pans_{tag}.txt"
+        # the list announces the sizes; P001's is too small in the `bad` run (the files hold 75 observations, the capacity is 70)
+        plist.write_text("".join(f"{p} {n if not (tag == 'bad' and p == 'P001') else 20}\n" for p, n in zip(pans, Ns)))
+        lists[tag] = str(plist)
+    out_ref = run(["--cfg", ref["cfg"], "--pan-list", lists["ref"], "--resident", "3", "--pin-route"])
+    r = subprocess.run([EXE, "--cfg", bad["cfg"], "--pan-list", lists["bad"], "--resident", "3", "--pin-route", "--max-n", "70"],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert "patient P002 skipped" in r.stdout and "more than the" in r.stdout and "2 patient(s) could not be read" in r.stdout
+    assert "lock-step batches" in out_ref and "lock-step batches" in r.stdout
+    for pan in pans:
+        fa, fb = ref["dirs"]["train"], bad["dirs"]["train"]
+        if pan in ("P002", "P001"):
+            assert open(os.path.join(fb, f"train_flag_{pan}.txt")).read() == "0\n"
+            assert not os.path.exists(os.path.join(fb, f"train_hyp_{pan}.bin"))
+            continue
+        for name in ("train_init_hyp_", "train_hyp_", "train_var_hyp_"):
+            a = open(os.path.join(fa, name + pan + ".bin"), "rb").read()
+            assert a and a == open(os.path.join(fb, name + pan + ".bin"), "rb").read(), (name, pan)
+        assert open(os.path.join(fb, f"train_flag_{pan}.txt")).read() == "1\n"
