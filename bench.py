@@ -65,7 +65,7 @@ def shape_traffic(label, kernel):
         return None
     if d.get("_meta", {}).get("csrc_sha256") != csrc_digest():
         return None
-    e = d.get("_shapes", {}).get(label, {}).get(kernel)
+    e = next((v for k, v in d.get("_shapes", {}).get(label, {}).items() if k.split("<")[0] == kernel), None)
     if not e or "write_bytes" not in e:
         return None
     return e["fetch_bytes_x2_if_wide_loads"] + e["write_bytes"]

@@ -35,5 +35,5 @@ with open(f"profiles/{rnd}_pipe_budget.txt", "w") as f:
             "of its time: the rest is the serial path of a workgroup (64 pivots per panel on one wave, panel solve, panel init) that the second\n"
             "workgroup on the CU only partly covers, and 5.1 GB of HBM traffic per launch (3.2 x the algorithmic 1.6 GB: left-looking history\n"
             "re-reads).  Folding the assembly into its idle slots was priced in round 5 and costs four times what it saves\n"
-            f"(profiles/{rnd}_cholinv_fused_asm_price.txt).\n")
+            "(profiles/r05_kernel_experiments.txt).\n")
 print(open(f"profiles/{rnd}_pipe_budget.txt").read())
