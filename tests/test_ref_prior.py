@@ -214,3 +214,18 @@ def test_oracle_prior_stage_matches_the_compiled_c_inference_prior(ref_inf):
                 assert clamp.any(), c["name"]
         else:
             assert set(c["dnlml"]) == {-777.0}                            # no gradient asked: dnlml untouched
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/medgpc/src"), reason="the reference tree exists in the build container only")
+def test_fixtures_regenerate_from_the_reference_sources():
+    """Where /root/reference exists: rebuild oracle/_ref from the reference's sources as they lie (make -C oracle ref: plain g++, no
+    stand-in headers) and run both drivers -- the committed fixtures are exactly what they print."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL)
+    for exe, name in (("ref_prior_dump", "ref_prior.json.gz"), ("ref_prior_inference_dump", "ref_prior_inference.json.gz")):
+        out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", exe)], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        with gzip.open(os.path.join(HERE, "golden", name), "rb") as f:
+            assert f.read() == out, name
+    # the three translation units come from the reference tree itself, compiled with nothing but its own include path
+    mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+    assert "$(REF)/prior/c_prior.cpp" in mk and "$(REF)/core/c_hyperparam.cpp" in mk and "$(REF)/inference/c_inference_prior.cpp" in mk
+    assert "-I$(REF)" in mk and "mkl" not in mk.split("REFCXXFLAGS")[1].split("\n")[0].lower()
