@@ -319,6 +319,8 @@ def ragged_cohort(out, dev_index, seed, reps=5):
             os.environ.update(env)
             ctx = medgp_amd.Context(7, Q, D, R, device=dev_index)     # (the switches are read at creation)
             ctx.reserve(P, int(ns.max()), P)
+            if name != "before":
+                ctx.reserve_plan(ns)          # the per-entry buffers sized once from the sizes (5.5 GB; the capacities alone would ask for 2 x 83 GB)
             ctx.set_patients(slots, pts)
             ctx.set_prior(-1, *synth.hier_gamma_prior(Q, D, R, 0.01))
             nl, g, st = ctx.nlml_grad(slots, th, True)
@@ -504,7 +506,7 @@ def host_paths(out, dev_index, seed):
             m1 = re.search(r"optimization finished: (\d+) nlml\+grad evaluations in (\d+) lock-step batches", r.stdout)
             m3 = re.search(r"continuous admission: (\d+) patients through (\d+) resident slots in (\d+) admissions \(([0-9.e+-]+) s, of which screening ([0-9.e+-]+) s for (\d+) nlml-only", r.stdout)
             m4 = re.search(r"outside admissions: ([0-9.e+-]+); of the whole loop: ([0-9.e+-]+)", r.stdout)
-            m5 = re.search(r"device memory: ([0-9.e+-]+) s in (\d+) management calls \(([0-9.e+-]+) s of it announcing the sizes up front\), ([0-9.e+-]+) GB mapped", r.stdout)
+            m5 = re.search(r"device memory: ([0-9.e+-]+) s in (\d+) management calls \(([0-9.e+-]+) s of it announcing the sizes up front\), ([0-9.e+-]+) GB held", r.stdout)
             return {"process_wall_s": wall, "gradient_evaluations": int(m1.group(1)) if m1 else None,
                     "lockstep_batches": int(m1.group(2)) if m1 else None, "screening_s": float(m3.group(5)) if m3 else None,
                     "screening_evaluations": int(m3.group(6)) if m3 else None,

@@ -101,9 +101,9 @@ int medgp_reserve(medgp_ctx *ctx, int max_slots, int max_n, int max_batch);
 int medgp_reserve_plan(medgp_ctx *ctx, int count, const int32_t *n, int ninit);
 
 /* Memory-management accounting of the context: wall seconds spent obtaining / releasing device memory so far, the number of such
- * calls, and the bytes currently mapped into the per-entry arenas.  Any pointer may be NULL.  (bench.py and medgp_train report it as
+ * calls, and the bytes the per-entry buffers (arenas) hold at present.  Any pointer may be NULL.  (bench.py and medgp_train report it as
  * `alloc_s`: time the host spent waiting for memory instead of queueing work.) */
-int medgp_alloc_stats(const medgp_ctx *ctx, double *seconds, int64_t *calls, int64_t *bytes_mapped);
+int medgp_alloc_stats(const medgp_ctx *ctx, double *seconds, int64_t *calls, int64_t *arena_bytes);
 
 /* Upload one patient (meta[i] in [0,D), t = time stamps, y = z-scored values; host pointers, copied).
  * Replaces c_objective_one's constructor, ref: util/c_objective_one.cpp:23-36 and

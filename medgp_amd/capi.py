@@ -184,12 +184,12 @@ class Context:
 
     def reserve_plan(self, sizes, ninit=0):
         """medgp_reserve_plan: announce the sizes of the patients that will be resident together (and the width of the screening):
-        the per-entry arenas are mapped once to what the largest call over them needs."""
+        the per-entry arenas are allocated once to what the largest call over them needs."""
         sizes = np.ascontiguousarray(sizes, dtype=np.int32)
         self._chk(self._lib.medgp_reserve_plan(self._h, int(sizes.shape[0]), _ptr(sizes, C.c_int32), int(ninit)))
 
     def alloc_stats(self):
-        """(seconds spent in device-memory management calls, number of such calls, bytes mapped into the per-entry arenas)"""
+        """(seconds spent in device-memory management calls, number of such calls, bytes held by the per-entry arenas)"""
         s, n, b = C.c_double(0.0), C.c_int64(0), C.c_int64(0)
         self._chk(self._lib.medgp_alloc_stats(self._h, C.byref(s), C.byref(n), C.byref(b)))
         return s.value, n.value, b.value

@@ -86,7 +86,7 @@ constexpr int kAuxStreams = 4;
 //     GPU), asks for 1.5 x and retries with exactly what is needed if that fails.
 struct Arena {
     char *base = nullptr;
-    size_t mapped = 0;   // bytes usable
+    size_t bytes = 0;    // size of the block
 };
 constexpr size_t kArenaEager = (size_t)8 << 30;
 enum ArenaId { AR_K = 0, AR_U, AR_Z, AR_ALPHA, AR_WDIAG, AR_CS, AR_SN, AR_SLAB, AR_LA_PART, AR_LA_SMALL, AR_COUNT };
@@ -138,7 +138,7 @@ struct medgp_ctx {
     int last_nbatch = 0;
     BatchPlan plan;                 // of the last call
     // arenas of the per-entry buffers (Kmat, Linv, z, alpha, wdiag, cs, sn, slab, look-ahead scratch): what medgp_reserve's capacities
-    // would need at most (full_*: the size of the address reservation).  Up to kArenaEager bytes they are mapped by medgp_reserve; beyond
+    // would need at most (full_*).  Up to kArenaEager bytes they are allocated by medgp_reserve; beyond
     // that (a ragged cohort whose largest patient is far above the median: max_batch x max_n^2 would not fit 288 GB) they grow with the
     // calls or are sized once by medgp_reserve_plan (struct Arena).
     size_t full_mat = 0, full_vec = 0, full_tab = 0, full_slab = 0;
@@ -188,7 +188,7 @@ struct medgp_ctx {
     // second lane of medgp_screen (round 6): chunks alternate between c->stream and s_screen1, each with its own rows of the batch
     // buffers and its own half of the arenas -- the assembly of one chunk runs beside the factorisation of the other
     hipStream_t s_screen1 = nullptr;
-    hipEvent_t ev_fork1 = nullptr, ev_screen0 = nullptr, ev_screen1 = nullptr;
+    hipEvent_t ev_fork1 = nullptr, ev_screen0 = nullptr;
     int screen_lanes = 2;           // MEDGP_SCREEN_LANES=1: one lane (rounds 1-5)
     char *h_screen_tab = nullptr;   // pinned: the slot / position / theta-row tables of ALL chunks of one medgp_screen call
     size_t screen_tab_cap = 0;
@@ -496,10 +496,10 @@ int sync_ctx_streams(medgp_ctx *c) {
 // retry at exactly `bytes`.  *moved is set when the block was replaced: its contents are gone.
 int arena_ensure(medgp_ctx *c, int id, size_t bytes, size_t limit, bool exact, bool *moved) {
     Arena &A = c->arena[id];
-    if (bytes <= A.mapped) return MEDGP_OK;
+    if (bytes <= A.bytes) return MEDGP_OK;
     AllocTimer tm(c);
     // nothing of this context may still read the old block (its streams, not the device: other contexts keep running)
-    const size_t old = A.mapped;
+    const size_t old = A.bytes;
     if (A.base) { int rc = sync_ctx_streams(c); if (rc) return rc; (void)hipFree(A.base); }
     A = Arena{};
     size_t want = exact ? bytes : std::max(bytes, old + old / 2);
@@ -508,7 +508,7 @@ int arena_ensure(medgp_ctx *c, int id, size_t bytes, size_t limit, bool exact, b
     hipError_t e = hipMalloc(&q, want);
     if (e != hipSuccess && want > bytes) { (void)hipGetLastError(); want = bytes; e = hipMalloc(&q, want); }   // near capacity the 1.5 x request can fail where `bytes` fits
     if (e != hipSuccess) return fail(c, MEDGP_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
-    A.base = (char *)q; A.mapped = want;
+    A.base = (char *)q; A.bytes = want;
     if (moved) *moved = true;
     return MEDGP_OK;
 }
@@ -947,7 +947,7 @@ int medgp_create(medgp_ctx **out, int device, int kernel_index, int Q, int D, in
     }
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     (void)hipStreamCreateWithFlags(&c->s_screen1, hipStreamNonBlocking);
-    for (hipEvent_t *e : {&c->ev_fork1, &c->ev_screen0, &c->ev_screen1}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
+    for (hipEvent_t *e : {&c->ev_fork1, &c->ev_screen0}) (void)hipEventCreateWithFlags(e, hipEventDisableTiming);
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess) c->num_cu = pr.multiProcessorCount; }
     *out = c;
     return MEDGP_OK;
@@ -966,7 +966,7 @@ void medgp_destroy(medgp_ctx *c) {
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->s_screen1) { (void)hipStreamSynchronize(c->s_screen1); (void)hipStreamDestroy(c->s_screen1); }
-    for (hipEvent_t e : {c->ev_fork1, c->ev_screen0, c->ev_screen1}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c->ev_fork1, c->ev_screen0}) if (e) (void)hipEventDestroy(e);
     if (c->h_screen_tab) (void)hipHostFree(c->h_screen_tab);
     for (hipStream_t st : {c->s_up, c->s_down}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (int i = 0; i < 2; i++) { if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]); if (c->ev_k[i]) (void)hipEventDestroy(c->ev_k[i]); }
@@ -1072,8 +1072,8 @@ int medgp_reserve(medgp_ctx *c, int max_slots, int max_n, int max_batch) {
             c->screen_budget = std::min(c->screen_budget, c->mem_budget);
         }
     }
-    // every configuration whose capacities stay below 8 GB of matrices (all of BASELINE.json's) is mapped in full here; beyond that
-    // (a ragged cohort: max_batch x max_n^2 would not fit) the arenas start empty and grow with the calls, or with medgp_reserve_plan
+    // every configuration whose capacities stay below 8 GB of matrices (all of BASELINE.json's) is allocated in full here; beyond that
+    // (a ragged cohort: max_batch x max_n^2 would not fit) the arenas start as token blocks and are sized by medgp_reserve_plan, or grow with the calls
     if (2 * c->full_mat * sizeof(double) <= kArenaEager) rc = ensure_arena(c, c->full_mat, c->full_mat, c->full_vec, c->full_tab, c->full_slab, true);
     else rc = ensure_arena(c, 0, 0, 0, 0, 0, true);   // (a token block each: the views never hold null pointers)
     if (rc) return rc;
@@ -1151,11 +1151,11 @@ int medgp_reserve_plan(medgp_ctx *c, int count, const int32_t *n, int ninit) {
     return MEDGP_OK;
 }
 
-int medgp_alloc_stats(const medgp_ctx *c, double *seconds, int64_t *calls, int64_t *bytes_mapped) {
+int medgp_alloc_stats(const medgp_ctx *c, double *seconds, int64_t *calls, int64_t *arena_bytes) {
     if (!c) return MEDGP_ERR_ARG;
     if (seconds) *seconds = c->alloc_s;
     if (calls) *calls = c->alloc_calls;
-    if (bytes_mapped) { int64_t b = 0; for (int i = 0; i < AR_COUNT; i++) b += (int64_t)c->arena[i].mapped; *bytes_mapped = b; }
+    if (arena_bytes) { int64_t b = 0; for (int i = 0; i < AR_COUNT; i++) b += (int64_t)c->arena[i].bytes; *arena_bytes = b; }
     return MEDGP_OK;
 }
 

@@ -368,7 +368,7 @@ static int train_main(int argc, const char *argv[]) {
     const size_t bufcap = std::min<size_t>((size_t)resident, std::max<size_t>((size_t)max_batch, gcap));   // (a merged group may hold everybody that is left)
     // ---------------- the device's per-entry arenas, sized ONCE (round 6): the largest lock-step call is a group of the gcap largest
     // patients of the list (it is walked longest first; a merged tail group holds fewer and smaller ones), the largest screening chunks
-    // are theirs too -- medgp_reserve_plan lays both out on the sizes alone and maps that much.  Obtaining device memory can take seconds
+    // are theirs too -- medgp_reserve_plan lays both out on the sizes alone and allocates that much.  Obtaining device memory can take seconds
     // on this platform when an earlier process has used it (medgp_hip.h); that wait now happens here, not inside the loop.
     double t_plan = 0.0;
     {
@@ -550,7 +550,7 @@ static int train_main(int argc, const char *argv[]) {
         double as = 0.0; int64_t an = 0, ab = 0;
         if (medgp_alloc_stats(ctx, &as, &an, &ab) == 0)
             cout << "INFO: device memory: " << as << " s in " << an << " management calls (" << t_plan << " s of it announcing the sizes up front), "
-                 << (double)ab / 1073741824.0 << " GB mapped into the per-entry arenas" << endl;
+                 << (double)ab / 1073741824.0 << " GB held by the per-entry arenas" << endl;
     }
     if (n_unreadable) cout << "ERROR: " << n_unreadable << " patient(s) could not be read or exceeded the announced size; they were skipped (flag 0)" << endl;
     if (ctx) medgp_destroy(ctx);
