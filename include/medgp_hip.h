@@ -83,8 +83,8 @@ int medgp_set_stream(medgp_ctx *ctx, void *hip_stream);
  * inference/c_inference_exact.cpp:66-68,168. Existing patients are discarded.
  * The per-entry matrices (two padded n x n fp64 matrices per batch entry) are allocated here when max_batch x max_n^2 of them stay
  * below 8 GB; beyond that (a cohort whose largest patient is far above the rest) they are sized once by medgp_reserve_plan from the
- * patients' sizes, or grown by the calls to what their size classes need (see medgp_last_plan) -- a call that outgrows a buffer waits
- * for this context's streams (not the device), replaces it and drops the factors of earlier calls.  A call whose matrices exceed the memory budget (64 GB, at most 70 % of what the device has free;
+ * patients' sizes, or grown by the calls to what their size classes need (see medgp_last_plan) -- a call that outgrows a buffer replaces
+ * it without waiting for anything (the old block is released at the context's next idle point) and drops the factors of earlier calls.  A call whose matrices exceed the memory budget (64 GB, at most 70 % of what the device has free;
  * MEDGP_MEM_BUDGET_GB) is run as consecutive waves of size classes that reuse the arenas; calls whose OUTPUTS need every entry's matrix
  * afterwards (MEDGP_FLAG_KEEP_FACTOR, medgp_factor_batch, medgp_fit_predict_batch) fail with MEDGP_ERR_CAPACITY instead. */
 int medgp_reserve(medgp_ctx *ctx, int max_slots, int max_n, int max_batch);

@@ -82,8 +82,9 @@ constexpr int kAuxStreams = 4;
 //     device's free-memory counter as if it were memory (one 256 GB reservation: "Free memory set to zero", every later call fails),
 //     and re-mapping chunks into a larger range left stale translations behind -- a later range read another arena's data
 //     (vmm_stress: mismatches in every arena after the first).  Plain blocks it is.
-//   * A growth waits for the CONTEXT's streams, not the device (hipDeviceSynchronize stalled every other context / rank sharing the
-//     GPU), asks for 1.5 x and retries with exactly what is needed if that fails.
+//   * A growth waits for NOTHING: the outgrown block is retired (queued kernels may still read it) and freed at the context's next idle
+//     point (round 5: hipDeviceSynchronize + hipFree first -- every other context sharing the GPU stalled); it asks for 1.5 x and
+//     retries with exactly what is needed if that fails.
 struct Arena {
     char *base = nullptr;
     size_t bytes = 0;    // size of the block
@@ -146,6 +147,10 @@ struct medgp_ctx {
     size_t mem_budget = (size_t)64 << 30;   // bytes of per-entry matrices one wave of a call may use (MEDGP_MEM_BUDGET_GB)
     size_t screen_budget = (size_t)2 << 30; // the same for one chunk of medgp_screen (MEDGP_SCREEN_BUDGET_GB)
     long long screen_work = 32768;  // block pairs (sum nb^2) at which a medgp_screen chunk of look-ahead entries is closed (MEDGP_SCREEN_WORK)
+    // blocks that outgrown arenas left behind: kernels queued before the growth may still read them, so they are NOT freed there (no
+    // wait at the growth) but at the next point where the context's streams are known to be idle (free_retired)
+    std::vector<void *> retired;
+    size_t retired_bytes = 0;
     double alloc_s = 0.0;           // wall seconds inside device / pinned memory management calls (medgp_alloc_stats)
     long long alloc_calls = 0;
     int *d_bpos = nullptr;
@@ -235,6 +240,9 @@ void free_all(medgp_ctx *c) {
     for (void *p : c->allocs) (void)hipFree(p);
     c->allocs.clear();
     for (int i = 0; i < AR_COUNT; i++) arena_release(c, c->arena[i]);
+    for (void *p : c->retired) (void)hipFree(p);
+    c->retired.clear();
+    c->retired_bytes = 0;
 }
 
 int num_cov(int kidx, int Q, int D, int R) {
@@ -491,21 +499,40 @@ int sync_ctx_streams(medgp_ctx *c) {
     return MEDGP_OK;
 }
 
+// the blocks outgrown arenas left behind; the caller guarantees that every stream of the context is idle
+void free_retired(medgp_ctx *c, bool timed = true) {
+    if (c->retired.empty()) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (void *p : c->retired) (void)hipFree(p);
+    if (timed) { c->alloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); c->alloc_calls++; }
+    c->retired.clear();
+    c->retired_bytes = 0;
+}
+
 // make at least `bytes` of arena `id` usable.  exact: the caller knows this is the high-water mark (medgp_reserve, medgp_reserve_plan):
 // allocate just that; otherwise 1.5 x what was there (at most `limit` bytes, the most the capacities of medgp_reserve allow), with a
 // retry at exactly `bytes`.  *moved is set when the block was replaced: its contents are gone.
+// The old block is RETIRED, not freed: kernels queued earlier may still read it, and neither they nor anything else is waited for here
+// (round 5 synchronised the whole device and freed first).  Retired blocks are freed at the next idle point of the context (the end of a
+// blocking call, medgp_synchronize), at once when they add up to more than half the memory budget, or when the device is out of memory.
 int arena_ensure(medgp_ctx *c, int id, size_t bytes, size_t limit, bool exact, bool *moved) {
     Arena &A = c->arena[id];
     if (bytes <= A.bytes) return MEDGP_OK;
     AllocTimer tm(c);
-    // nothing of this context may still read the old block (its streams, not the device: other contexts keep running)
     const size_t old = A.bytes;
-    if (A.base) { int rc = sync_ctx_streams(c); if (rc) return rc; (void)hipFree(A.base); }
+    if (A.base) { c->retired.push_back(A.base); c->retired_bytes += A.bytes; }
     A = Arena{};
+    if (c->retired_bytes > c->mem_budget / 2) { int rc = sync_ctx_streams(c); if (rc) return rc; free_retired(c, false); }
     size_t want = exact ? bytes : std::max(bytes, old + old / 2);
     if (limit >= bytes) want = std::min(want, limit);
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, want);
+    if (e != hipSuccess && !c->retired.empty()) {   // out of memory with retired blocks around: give them back first
+        (void)hipGetLastError();
+        int rc = sync_ctx_streams(c); if (rc) return rc;
+        free_retired(c, false);
+        e = hipMalloc(&q, want);
+    }
     if (e != hipSuccess && want > bytes) { (void)hipGetLastError(); want = bytes; e = hipMalloc(&q, want); }   // near capacity the 1.5 x request can fail where `bytes` fits
     if (e != hipSuccess) return fail(c, MEDGP_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
     A.base = (char *)q; A.bytes = want;
@@ -1006,6 +1033,7 @@ int medgp_synchronize(medgp_ctx *c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->s_down) HIPCHK(c, hipStreamSynchronize(c->s_down));   // (result downloads of the asynchronous lanes)
+    free_retired(c);   // (every kernel of the context is queued on, or joined into, its stream: idle now)
     return MEDGP_OK;
 }
 
@@ -1420,6 +1448,7 @@ int medgp_nlml_grad(medgp_ctx *c, int nbatch, const int32_t *slots, const double
         std::memcpy(nlml, hn, sizeof(double) * nbatch);
         if (want_grad) std::memcpy(grad, hg, sizeof(double) * nbatch * H);
         if (status) std::memcpy(status, hs, sizeof(int32_t) * nbatch);
+        free_retired(c);   // (the stream is idle: blocks that outgrown arenas left behind can go)
         return MEDGP_OK;
     }
     // (this path shares lane 0's result staging: a download of that lane still in flight on the copy stream must have read it first)
@@ -1431,6 +1460,7 @@ int medgp_nlml_grad(medgp_ctx *c, int nbatch, const int32_t *slots, const double
     if (want_grad) HIPCHK(c, hipMemcpyAsync(grad, c->d_grad, sizeof(double) * nbatch * H, hipMemcpyDeviceToHost, c->stream));
     if (status) HIPCHK(c, hipMemcpyAsync(status, c->d_status_out, sizeof(int32_t) * nbatch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_retired(c);
     return MEDGP_OK;
 }
 
@@ -1560,6 +1590,7 @@ int medgp_screen(medgp_ctx *c, int nslots, const int32_t *slots, int ninit, cons
         HIPCHK(c, hipStreamSynchronize(c->s_screen1));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_retired(c);
     if (rc) return rc;
     for (int sp = 0; sp < nslots; sp++) {   // walk order -> the caller's rows
         std::memcpy(nlml + (size_t)perm[sp] * ninit, hn + (size_t)sp * ninit, sizeof(double) * ninit);

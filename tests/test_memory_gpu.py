@@ -1,5 +1,5 @@
 """Device memory of a context (round 6): per-entry buffers sized ONCE where the sizes are known (medgp_reserve_plan, from the patients'
-sizes), grown without a device-wide wait where they are not, nlml-only calls that never touch Linv, and memory WAVES for calls whose
+sizes), grown without any wait where they are not (outgrown blocks are retired and freed at the next idle point), nlml-only calls that never touch Linv, and memory WAVES for calls whose
 per-entry matrices exceed the budget.  None of it may change a bit of the results: every check here is against the same call on a
 context that took the other path, bit for bit (one factorisation schedule pinned where the comparison crosses batch compositions),
 and against the oracle at the parity bars of test_parity_gpu.py.
