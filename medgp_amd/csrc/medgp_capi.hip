@@ -1176,6 +1176,9 @@ int medgp_reserve_plan(medgp_ctx *c, int count, const int32_t *n, int ninit) {
     if ((rc = ensure_arena(c, nk, nu, nvec, ntab, nslab, true))) return rc;
     if (npart && (rc = arena_ensure(c, AR_LA_PART, npart * sizeof(double), 0, true, nullptr))) return rc;
     if (nsmall && (rc = arena_ensure(c, AR_LA_SMALL, nsmall * sizeof(double), 0, true, nullptr))) return rc;
+    // a set-up call: wait for the context's streams once and give the replaced blocks back now, so that the loop that follows starts with
+    // nothing left to release
+    if (!c->retired.empty()) { if ((rc = sync_ctx_streams(c))) return rc; free_retired(c); }
     return MEDGP_OK;
 }
 
