@@ -162,7 +162,8 @@ int medgp_screen(medgp_ctx *ctx, int nslots, const int32_t *slots, int ninit, co
  * EVERY route: the one-workgroup-per-patient kernel runs the reference's jitter loop (ref: inference/c_inference_exact.cpp:
  * 99-111) in-kernel, and the multi-CU schedule used for few, large entries (at most 0.6 x #CU entries with n > 64) hands the
  * entries whose single attempt failed to that same in-kernel loop on the device (k_cholinv, sel = 2) -- the host reads no
- * status back.  (Only growing the multi-CU scratch for a larger batch / n than any call before waits for the device once.) */
+ * status back, and a call that has to grow a buffer waits for nothing either (round 6: the outgrown block is released at the
+ * context's next idle point). */
 int medgp_nlml_grad_device(medgp_ctx *ctx, int nbatch, const int32_t *slots, const double *theta_dev,
                            int flag_grad, double *nlml_dev, double *grad_dev, int32_t *status_dev);
 

@@ -475,7 +475,7 @@ int d2h_pinned(medgp_ctx *c, const void *dev, size_t bytes, const char **out) {
     return MEDGP_OK;
 }
 
-// ---- arenas: reserve once, map more behind what is there, never move (see struct Arena) ----------------------------------------
+// ---- arenas: one block each, sized once where possible, replaced (never waited for) where not (see struct Arena) ----------------
 struct AllocTimer {   // wall time of the memory-management calls, for medgp_alloc_stats
     medgp_ctx *c;
     std::chrono::steady_clock::time_point t0;
@@ -575,7 +575,7 @@ int ensure_la(medgp_ctx *c, std::vector<LaNeed> &v, bool with_u, size_t part0 = 
     size_t need_part = part0, need_small = small0;   // (part0 / small0: the lane base of the plan, doubles)
     for (const LaNeed &e : v) { need_part += la_part_doubles(e, with_u); need_small += la_small_doubles(e); }
     int rc;
-    // (a block that must grow is replaced: arena_ensure waits for the context's streams first -- queued kernels may still read it)
+    // (a block that must grow is replaced; the old one is retired, not freed: kernels queued on any of the context's streams may still read it)
     if ((rc = arena_ensure(c, AR_LA_PART, need_part * sizeof(double), 0, false, nullptr))) return rc;
     if ((rc = arena_ensure(c, AR_LA_SMALL, need_small * sizeof(double), 0, false, nullptr))) return rc;
     double *pp = (double *)c->arena[AR_LA_PART].base + part0, *ps = (double *)c->arena[AR_LA_SMALL].base + small0;
@@ -810,10 +810,10 @@ void la_needs(const BatchPlan &P, const std::vector<LaNeed> &las, const std::vec
 // N = 5832: 3 entries = 0.83 GB of matrices + 0.42 GB of scratch per chunk where round 5 took 32 entries = 26 GB + 9 GB (obtaining
 // that much memory can cost seconds, see struct Arena).  The budget (2 GB) still gives every size its efficient route: 1024 entries of N <= 512 (one workgroup each, two per
 // CU), 256 of N <= 1024 (one per CU), 64 of N <= 2048 (look-ahead schedule, saturated from 16 on).
-size_t screen_chunk_end(const medgp_ctx *c, const std::vector<int> &ns, int ninit, size_t e0, size_t total) {
+size_t screen_chunk_end(const medgp_ctx *c, const std::vector<int> &ns, int ninit, size_t e0, size_t total, int max_entries) {
     size_t e = e0, bytes = 0;
     long long work = 0;
-    while (e < total && (int)(e - e0) < c->max_batch) {
+    while (e < total && (int)(e - e0) < max_entries) {
         const int nb = blocks64(ns[e / ninit]);
         const size_t ldb = (size_t)64 << size_bucket(nb), per = 8 * ldb * ldb;
         if (e > e0 && bytes + per > c->screen_budget) break;
@@ -832,16 +832,12 @@ struct ScreenCut {
     int lane_rows = 0;
     size_t cap_mat = 0, cap_vec = 0, cap_tab = 0, cap_part = 0, cap_small = 0;
 };
-void screen_cut(medgp_ctx *c, const std::vector<int> &walk_n, int ninit, ScreenCut &S) {
+void screen_cut(const medgp_ctx *c, const std::vector<int> &walk_n, int ninit, ScreenCut &S) {
     const size_t total = walk_n.size() * (size_t)ninit;
-    const int saved_batch = c->max_batch;
-    S.two = c->screen_lanes >= 2 && c->max_batch >= 2 && screen_chunk_end(c, walk_n, ninit, 0, total) < total;
-    S.lane_rows = S.two ? c->max_batch / 2 : c->max_batch;
-    c->max_batch = S.lane_rows;   // (screen_chunk_end's entry cap)
+    S.two = c->screen_lanes >= 2 && c->max_batch >= 2 && screen_chunk_end(c, walk_n, ninit, 0, total, c->max_batch) < total;
+    S.lane_rows = S.two ? c->max_batch / 2 : c->max_batch;   // a lane's rows of the batch-indexed buffers = its chunks' entry cap
     S.chunks.clear();
-    for (size_t e0 = 0; e0 < total;) { const size_t e = screen_chunk_end(c, walk_n, ninit, e0, total); S.chunks.push_back({e0, e}); e0 = e; }
-    c->max_batch = saved_batch;
-    if (S.chunks.size() < 2) S.two = false;
+    for (size_t e0 = 0; e0 < total;) { const size_t e = screen_chunk_end(c, walk_n, ninit, e0, total, S.lane_rows); S.chunks.push_back({e0, e}); e0 = e; }
     BatchPlan P;
     std::vector<LaNeed> las;
     std::vector<int> la_of, en;
