@@ -156,3 +156,38 @@ def test_growing_the_buffers_changes_no_bit():
     for x, y in zip(a[2], b[2]):
         assert np.array_equal(np.asarray(x), np.asarray(y))
     assert a[3] > b[3]        # the unplanned context went back to the allocator between the calls
+
+
+def test_growth_under_an_asynchronous_lane_in_flight():
+    """A blocking call outgrows every buffer while an asynchronous lane's kernels -- queued just before, on the same buffers -- may still
+    be running: the outgrown blocks are retired, not freed, so the lane's results are those of an undisturbed context, bit for bit, and
+    so are the blocking call's.  (Round 5 synchronised the device and freed at this point.)"""
+    sizes = SIZES
+    pts, th = _cohort(sizes)
+    small = np.array([1, 4, 6, 9, 10])            # N <= 90
+    allp = np.arange(len(sizes))
+
+    ref = _ctx(sizes, pts)
+    want_small = ref.nlml_grad(small, th[small], True)
+    want_all = ref.nlml_grad(allp, th, True)
+    ref.close()
+
+    for rep in range(3):
+        ctx = medgp_amd.Context(7, Q, D, R)
+        ctx.reserve(len(sizes), 6000, 64)          # buffers on demand
+        ctx.set_patients(allp, pts)
+        ctx.set_prior(-1, *synth.hier_gamma_prior(Q, D, R, 0.01))
+        H = ctx.H
+        b = dict(th=ctx.pinned((len(small), H), np.float64), nl=ctx.pinned((len(small),), np.float64), gr=ctx.pinned((len(small), H), np.float64),
+                 st=ctx.pinned((len(small),), np.int32))
+        b["th"][:] = th[small]
+        b["gr"][:] = -7.0
+        ctx.nlml_grad_async(rep % 2, small, b["th"], True, b["nl"], b["gr"], b["st"])   # sizes the buffers for five small patients
+        got_all = ctx.nlml_grad(allp, th, True)                                         # ... and this one outgrows all of them at once
+        ctx.wait(rep % 2)
+        s = ctx.alloc_stats()
+        ctx.close()
+        for x, y in zip(want_all, got_all):
+            assert np.array_equal(x, y)
+        assert np.array_equal(b["nl"], want_small[0]) and np.array_equal(b["gr"], want_small[1]) and np.array_equal(b["st"], want_small[2])
+        assert s[2] > 0
