@@ -856,8 +856,12 @@ def main():
                      "kernel_ms_per_step_source": "%d untimed steps behind the timed region, events around every launch; avg_launch_ms: live over the timed region" % n_split})
         f_alg = N ** 3 + 6 * N * N + 80 * Q * N * (N + 1) / 2
         rank_ms = [r["ms_per_step"] for r in seen]
+        try:   # RCCL's version when the nccl backend carried the barrier / reductions (verdict r5 item 5)
+            nccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:   # noqa: BLE001
+            nccl_version = None
         extra = {
-            "ranks_seen": seen, "backend": backend,
+            "ranks_seen": seen, "backend": backend, "nccl_version": nccl_version,
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "mean": sum(rank_ms) / len(rank_ms)},
             "roofline": roof,
             "end_to_end": {"flop_per_eval": f_alg, "tflops": f_alg * value / world / 1e12,

@@ -103,7 +103,8 @@ def test_one_rank_under_torchrun_runs_the_rccl_path(tmp_path):
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["backend"] == "nccl" and line["n_gpus"] == 1 and len(line["ranks_seen"]) == 1
-    assert plain["backend"] == "none"
+    assert line["nccl_version"] and line["nccl_version"][0].isdigit()          # RCCL reported its version: it was really initialised
+    assert plain["backend"] == "none" and plain["nccl_version"] is None
     d = np.load(f"{dump}.rank0.npz")
     for g, nl, gs, st in zip(d["gids"], d["nlml"], d["gsum"], d["status"]):
         assert r0[int(g)] == (nl, gs, int(st))
